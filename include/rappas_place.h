@@ -1,0 +1,156 @@
+/*
+ * rappas_place.h -- C ABI of the MI355X-native phylo-kmer placement engine.
+ *
+ * Drop-in boundary for RAPPAS's query-placement hot path (`-p p`).  The reference (Java) has no
+ * FFI seam; the boundary is cut where SURVEY.md section 8(b) puts it.  Paths below are relative to
+ * the reference root.  Each entry point names the reference code it replaces; INTEGRATION.md shows
+ * the JNI stub a RAPPAS maintainer would add on the Java side.
+ *
+ *   rk_db_create          <- the lookup structure behind session.hash:
+ *                            src/core/hash/CustomHash_v4_FastUtil81.java:36,146-153 (+ HashStrategy.java:22-29)
+ *                            fed from the walk SessionNext_v2.saveToJSON does (src/main_v2/SessionNext_v2.java:250-261)
+ *                            and the scalars of src/main_v2/SessionNext_v2.java:43-66 (k, states, PPStarThreshold*).
+ *   rk_place_batch        <- the per-read body of PlacementProcess.processQueries,
+ *                            src/core/algos/PlacementProcess.java:645-1025 (knife init, k-mer loop, accumulate,
+ *                            ambiguity mean/max :1129-1236, fillBestScoreList :396-451, LWR + keep-factor :974-1025),
+ *                            with src/core/algos/AmbigSequenceKnife.java:98-272 and
+ *                            src/core/DNAStatesShifted.java:115-143,182-243 / src/core/AAStates.java:48-197 underneath.
+ *   rk_pack_reads_device  <- AmbigSequenceKnife.initTables char->state part (AmbigSequenceKnife.java:103-130) as a
+ *                            device kernel: ASCII -> 2-bit / 5-bit packed records + per-read flags.
+ *   rk_place_packed_device<- same body as rk_place_batch for reads already packed and resident in HBM.
+ *
+ * Conventions: plain C types only; inputs are borrowed for the duration of a call, outputs are
+ * caller-owned; return 0 on success, <0 on error with a message in rk_last_error() (thread-local);
+ * the library never calls exit().  The product path has no CPU fallback: every entry point that
+ * computes placements requires a HIP device and fails with RK_ERR_NO_DEVICE otherwise.
+ */
+#ifndef RAPPAS_PLACE_H
+#define RAPPAS_PLACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RK_VERSION 100 /* 0.1.0 */
+
+/* alphabets = number of unambiguous states (States.getNonAmbiguousStatesCount()) */
+#define RK_ALPHABET_DNA 4  /* src/core/DNAStatesShifted.java : A=0 T/U=1 C=2 G=3, 2 bits/base   */
+#define RK_ALPHABET_AA 20  /* src/core/AAStates.java : R H K D E S T N Q C G P A I L M F W Y V, 5 bits/residue */
+
+/* ambiguity handling (src/main_v2/ArgumentsParser_v2.java:90-91; PlacementProcess.java:738-749) */
+#define RK_AMB_SKIP 0 /* --noamb      */
+#define RK_AMB_MEAN 1 /* default      */
+#define RK_AMB_MAX 2  /* --ambwithmax */
+
+/* k-mer -> row lookup structure */
+#define RK_TABLE_AUTO 0   /* direct when sigma^k slots fit the budget, else hash */
+#define RK_TABLE_HASH 1   /* open-addressed (linear probing), 16-byte slots {key, row descriptor} */
+#define RK_TABLE_DIRECT 2 /* identity-hashed, collision-free special case: sigma^k 8-byte row descriptors */
+
+/* per-read result flags */
+#define RK_FLAG_PLACED 1u         /* >=1 k-mer matched (L non-empty, PlacementProcess.java:797) */
+#define RK_FLAG_BAD_CHAR 2u       /* unsupported character; the reference would System.exit(1) (AmbigSequenceKnife.java:124-128) */
+#define RK_FLAG_TOO_SHORT 4u      /* R < k : no k-mer (the reference crashes for R < k-1) */
+#define RK_FLAG_AMBIGUOUS 8u      /* read contains an ambiguity character */
+#define RK_FLAG_BELOW_NSBOUND 16u /* best score < ns_bound: no jplace record (PlacementProcess.java:974) */
+#define RK_FLAG_TOO_LONG 64u      /* device pack only: read longer than the packed record; not placed */
+
+/* error codes */
+#define RK_OK 0
+#define RK_ERR_INVALID -1
+#define RK_ERR_NO_DEVICE -2
+#define RK_ERR_HIP -3
+#define RK_ERR_NOMEM -4
+#define RK_ERR_UNSUPPORTED -5
+
+typedef struct rk_db rk_db;
+
+typedef struct rk_db_desc {
+    uint32_t alphabet;    /* RK_ALPHABET_DNA | RK_ALPHABET_AA */
+    uint32_t convert_uo;  /* AA only: U->C, O->L (src/core/AAStates.java:118-123) */
+    uint32_t k;           /* DNA: 2..15, AA: 2..12 */
+    uint32_t n_branches;  /* originalTree.getNodeCount() (PlacementProcess.java:495-496); branch ids < n_branches <= 65535 */
+    float thr_log10;      /* session.PPStarThresholdAsLog10 (T) */
+    float thr;            /* session.PPStarThreshold (P), used by the ambiguity-mean path */
+    uint64_t n_keys;
+    const uint64_t *key_codes;   /* [n_keys] DNA: sum state_i<<(2i) (== little-endian compressMer bytes); AA: sum state_i<<(5i) */
+    const uint64_t *row_offsets; /* [n_keys+1] CSR offsets into branch_ids/scores */
+    const uint16_t *branch_ids;  /* [n_entries] (char)nodeId of CustomHash_v4_FastUtil81.java:79,87; unique within a row */
+    const float *scores;         /* [n_entries] log10 PP*, finite */
+    int32_t device;              /* HIP device ordinal */
+    uint32_t table_mode;         /* RK_TABLE_* */
+} rk_db_desc;
+
+typedef struct rk_db_info {
+    uint32_t alphabet, k, n_branches, table_mode;
+    float thr_log10, thr;
+    uint64_t n_keys, n_entries;
+    uint64_t table_slots, table_bytes, rows_bytes; /* HBM footprint */
+    uint32_t bits_per_symbol, max_row_len;
+    int32_t device;
+} rk_db_info;
+
+typedef struct rk_params {
+    uint32_t keep_at_most; /* --keep-at-most, default 7 (ArgumentsParser_v2.java:87); 1..16 */
+    float keep_factor;     /* --keep-factor, default 0.01f (ArgumentsParser_v2.java:88) */
+    uint32_t amb_mode;     /* RK_AMB_* */
+    float ns_bound;        /* --nsbound / calibrationNormScore, default -INFINITY */
+} rk_params;
+
+typedef struct rk_counters {
+    uint64_t reads, placed, unplaced, bad_char, too_short, ambiguous;
+} rk_counters;
+
+/* Result arrays, n_reads x keep_at_most, rows ordered best -> worse and already cut by keep_factor.
+ * Unused rows: branch 0xFFFF, score -inf, lwr 0.  Host pointers for rk_place_batch, device pointers
+ * for rk_place_packed_device.  Tie rule (the reference's is map-layout dependent): score desc, branch id asc. */
+typedef struct rk_result {
+    uint8_t *n_rows;   /* [n_reads]   rows emitted (0 => unplaced or gated) */
+    uint16_t *branch;  /* [n_reads*K] original-tree node id of the edge's child */
+    float *score;      /* [n_reads*K] S[x], bit-exact float32 */
+    double *lwr;       /* [n_reads*K] likelihood weight ratio */
+    uint32_t *flags;   /* [n_reads]   RK_FLAG_* */
+} rk_result;
+
+int rk_version(void);
+const char *rk_last_error(void);
+
+/* Main_DBBUILD_3.java:165-166 (float32 threshold pair from omega, #states, k) */
+void rk_thresholds(float omega, uint32_t n_states, uint32_t k, float *thr, float *thr_log10);
+
+int rk_db_create(const rk_db_desc *desc, rk_db **out);
+void rk_db_destroy(rk_db *db);
+int rk_db_get_info(const rk_db *db, rk_db_info *info);
+
+/* Host-buffer entry point: ASCII reads (concatenated, seq_off[n_reads+1]) -> results in host memory.
+ * Internally: H2D, device-side pack, placement kernel(s), D2H; chunked to bound device memory. */
+int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
+                   const uint64_t *seq_off, rk_result *out, rk_counters *counters);
+
+/* Packed-record geometry for a given maximum read length: 32-bit words per record. */
+uint32_t rk_packed_words(const rk_db *db, uint32_t max_len);
+
+/* Device entry points (all pointers are device pointers on db's device; stream = hipStream_t or NULL).
+ * rk_pack_reads_device: ASCII -> packed records [n_reads][words_per_read] + lens[n_reads] + flags[n_reads]. */
+int rk_pack_reads_device(rk_db *db, uint64_t n_reads, const uint8_t *d_seq_ascii, const uint64_t *d_seq_off,
+                         uint32_t words_per_read, uint32_t *d_packed, uint32_t *d_lens, uint32_t *d_flags,
+                         void *stream);
+/* rk_place_packed_device: d_lens may be NULL (every read has fixed_len symbols); d_flags_in may be NULL
+ * (no read carries BAD_CHAR/AMBIGUOUS).  Reads flagged AMBIGUOUS need d_seq_ascii/d_seq_off (else they are
+ * reported unplaced with the flag set).  Asynchronous on `stream`. */
+int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_reads, const uint32_t *d_packed,
+                           uint32_t words_per_read, const uint32_t *d_lens, uint32_t fixed_len,
+                           const uint32_t *d_flags_in, const uint8_t *d_seq_ascii, const uint64_t *d_seq_off,
+                           const rk_result *d_out, void *stream);
+
+/* Launch geometry knob (0 = auto): lanes cooperating on one read (8,16,32,64). For tuning/benchmarks. */
+int rk_set_lanes_per_read(rk_db *db, uint32_t lanes);
+/* Name of the placement kernel variant the next launch will use (for profiles). */
+const char *rk_kernel_name(const rk_db *db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,64 @@
+// rk_device.h -- shared device-side definitions for the gfx950 placement kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rk {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// Row descriptor (8 B): (offset of the row in the rows blob, in 8-byte units) << 24 | row length.
+// len == 0 <=> k-mer absent.  40-bit offsets address 8 TiB of rows; rows hold < 2^24 entries.
+constexpr int DESC_LEN_BITS = 24;
+constexpr u32 DESC_LEN_MASK = (1u << DESC_LEN_BITS) - 1;
+
+// Row image in the blob (8-byte aligned): u16 branch[len] (padded to 4 B) | f32 score[len] | pad to 8 B.
+__host__ __device__ inline u64 row_bytes(u64 len) {
+    u64 b = ((len + 1) & ~1ull) * 2 + len * 4;
+    return (b + 7) & ~7ull;
+}
+
+// Untouched marker for the per-read LDS score vector (a NaN pattern no finite sum can produce).
+constexpr u32 S_UNTOUCHED = 0xFFFFFFFFu;
+
+struct DbView {
+    const u64 *direct;   // [sigma^k] row descriptors (RK_TABLE_DIRECT) or nullptr
+    const uint4 *slots;  // [hash_mask+1] {key+1 lo, key+1 hi, desc lo, desc hi} (RK_TABLE_HASH) or nullptr
+    u64 hash_mask;
+    const unsigned char *rows;
+    u32 k, bits, n_branches, alphabet;
+    float T, P;
+    u32 convert_uo;
+};
+
+struct PlaceArgs {
+    DbView db;
+    u64 n_reads;
+    const u32 *packed;
+    u32 words_per_read;
+    const u32 *lens;
+    u32 fixed_len;
+    const u32 *flags_in;
+    u32 has_ascii;  // ambiguous reads are handled by the ASCII kernel; leave their outputs alone
+    // params
+    u32 keep_at_most;
+    float keep_factor;
+    float ns_bound;
+    // outputs
+    unsigned char *o_nrows;
+    unsigned short *o_branch;
+    float *o_score;
+    double *o_lwr;
+    u32 *o_flags;
+    // geometry
+    u32 s_stride;  // u32 words per read score vector in LDS
+    u32 list_cap;  // row descriptors per read hit list in LDS
+};
+
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+}  // namespace rk

@@ -1,0 +1,625 @@
+// rk_engine.hip -- host side of the placement engine: DB image construction (open-addressed / direct table
+// + CSR row blob resident in HBM), launch geometry, and the C ABI of include/rappas_place.h.
+// Product path: there is NO CPU fallback in this file; every compute entry point needs a HIP device.
+#include "rk_kernels.hip"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rk;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                     \
+    } while (0)
+
+extern "C" const char *rk_last_error(void) { return g_err; }
+extern "C" int rk_version(void) { return RK_VERSION; }
+
+// Main_DBBUILD_3.java:165-166
+extern "C" void rk_thresholds(float omega, uint32_t n_states, uint32_t k, float *thr, float *thr_log10) {
+    float ratio = omega / (float)n_states;
+    float p = (float)std::pow(0.0 + (double)ratio, (double)k);
+    if (thr) *thr = p;
+    if (thr_log10) *thr_log10 = (float)std::log10((double)p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// alphabets (host tables uploaded with the DB)
+// DNA: src/core/DNAStatesShifted.java:45-96 (ambiguity sets), :182-209 (states).
+// AA : src/core/AAStates.java:23-28, :68-123.
+// ------------------------------------------------------------------------------------------------
+struct Alphabet {
+    unsigned char table[256];      // state | 0x80|class | 0xFF
+    unsigned char alts[16 * 20];   // alternatives per class
+    unsigned char alt_count[16];
+};
+
+static void build_alphabet(uint32_t alphabet, bool convert_uo, Alphabet &A) {
+    memset(A.table, 0xFF, sizeof(A.table));
+    memset(A.alts, 0, sizeof(A.alts));
+    memset(A.alt_count, 0, sizeof(A.alt_count));
+    auto both = [&](char up, unsigned char v) {
+        A.table[(unsigned char)up] = v;
+        A.table[(unsigned char)(up + 32)] = v;
+    };
+    if (alphabet == RK_ALPHABET_DNA) {
+        both('A', 0); both('T', 1); both('U', 1); both('C', 2); both('G', 3);
+        const unsigned char a = 0, t = 1, c = 2, g = 3;
+        struct { char ch; int n; unsigned char s[4]; } cls[] = {
+            {'R', 2, {a, g}}, {'Y', 2, {c, t}}, {'S', 2, {c, g}}, {'W', 2, {a, t}}, {'K', 2, {g, t}},
+            {'M', 2, {a, c}}, {'B', 3, {c, g, t}}, {'D', 3, {a, g, t}}, {'H', 3, {a, c, t}},
+            {'V', 3, {a, c, g}}, {'N', 4, {a, c, g, t}},
+        };
+        int ci = 0;
+        for (auto &e : cls) {
+            both(e.ch, (unsigned char)(0x80 | ci));
+            A.alt_count[ci] = (unsigned char)e.n;
+            for (int i = 0; i < e.n; i++) A.alts[ci * 20 + i] = e.s[i];
+            ci++;
+        }
+        // '.' and '-' : four never-filled (zero) alternatives
+        A.table[(unsigned char)'.'] = A.table[(unsigned char)'-'] = (unsigned char)(0x80 | ci);
+        A.alt_count[ci] = 4;
+    } else {
+        const char *order = "RHKDESTNQCGPAILMFWYV";
+        for (int i = 0; i < 20; i++) both(order[i], (unsigned char)i);
+        if (convert_uo) { both('U', 9); both('O', 14); }
+        // class 0: any
+        for (char ch : {'-', '*', '!', 'X', 'x'}) A.table[(unsigned char)ch] = 0x80;
+        A.alt_count[0] = 20;
+        for (int i = 0; i < 20; i++) A.alts[i] = (unsigned char)i;
+        both('B', 0x81); A.alt_count[1] = 2; A.alts[20 + 0] = 3;  A.alts[20 + 1] = 7;
+        both('Z', 0x82); A.alt_count[2] = 2; A.alts[40 + 0] = 4;  A.alts[40 + 1] = 8;
+        both('J', 0x83); A.alt_count[3] = 2; A.alts[60 + 0] = 13; A.alts[60 + 1] = 14;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DB object
+// ------------------------------------------------------------------------------------------------
+struct rk_db {
+    rk_db_info info{};
+    uint32_t convert_uo = 0;
+    DbView view{};
+    void *d_table = nullptr;
+    void *d_rows = nullptr;
+    unsigned char *d_alpha = nullptr;  // table[256] | alts[320] | alt_count[16]
+    uint32_t lanes_per_read = 0;       // 0 = auto
+    uint32_t waves_per_block = 1;
+    int cu_count = 256;
+    size_t lds_per_cu = 160 * 1024;
+    hipStream_t stream = nullptr;      // host-path stream
+    std::string kernel_name;
+};
+
+static uint64_t host_mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+static bool ipow_fits(uint64_t base, uint32_t e, uint64_t limit, uint64_t &out) {
+    uint64_t v = 1;
+    for (uint32_t i = 0; i < e; i++) {
+        if (v > limit / base) return false;
+        v *= base;
+    }
+    out = v;
+    return true;
+}
+
+extern "C" void rk_db_destroy(rk_db *db) {
+    if (!db) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(db->info.device);
+    if (db->d_table) (void)hipFree(db->d_table);
+    if (db->d_rows) (void)hipFree(db->d_rows);
+    if (db->d_alpha) (void)hipFree(db->d_alpha);
+    if (db->stream) (void)hipStreamDestroy(db->stream);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete db;
+}
+
+extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
+    if (!d || !out) return fail(RK_ERR_INVALID, "rk_db_create: null argument");
+    *out = nullptr;
+    if (d->alphabet != RK_ALPHABET_DNA && d->alphabet != RK_ALPHABET_AA)
+        return fail(RK_ERR_INVALID, "rk_db_create: alphabet must be 4 (DNA) or 20 (AA), got %u", d->alphabet);
+    const uint32_t bits = d->alphabet == RK_ALPHABET_DNA ? 2 : 5;
+    const uint32_t kmax = d->alphabet == RK_ALPHABET_DNA ? 15 : 12;
+    if (d->k < 2 || d->k > kmax)
+        return fail(RK_ERR_UNSUPPORTED, "rk_db_create: k=%u outside supported range 2..%u for this alphabet", d->k, kmax);
+    if (d->n_branches < 1 || d->n_branches > 65535)
+        return fail(RK_ERR_INVALID, "rk_db_create: n_branches=%u must be in 1..65535 (branch ids are 16-bit)", d->n_branches);
+    if (!std::isfinite(d->thr_log10) || !std::isfinite(d->thr))
+        return fail(RK_ERR_INVALID, "rk_db_create: thresholds must be finite");
+    if (d->n_keys && (!d->key_codes || !d->row_offsets)) return fail(RK_ERR_INVALID, "rk_db_create: null key arrays");
+    const uint64_t n_keys = d->n_keys;
+    const uint64_t n_entries = n_keys ? d->row_offsets[n_keys] : 0;
+    if (n_entries && (!d->branch_ids || !d->scores)) return fail(RK_ERR_INVALID, "rk_db_create: null entry arrays");
+    if (n_keys && d->row_offsets[0] != 0) return fail(RK_ERR_INVALID, "rk_db_create: row_offsets[0] must be 0");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RK_ERR_NO_DEVICE, "rk_db_create: no HIP device available (this engine has no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev)
+        return fail(RK_ERR_INVALID, "rk_db_create: device %d out of range (0..%d)", d->device, ndev - 1);
+
+    // ---- table mode ----
+    uint64_t space = 0;
+    const bool space_ok = ipow_fits(d->alphabet, d->k, 1ull << 40, space);
+    uint32_t mode = d->table_mode;
+    if (mode == RK_TABLE_AUTO) mode = (space_ok && space <= (1ull << 28)) ? RK_TABLE_DIRECT : RK_TABLE_HASH;
+    if (mode == RK_TABLE_DIRECT && !(space_ok && space <= (1ull << 31)))
+        return fail(RK_ERR_UNSUPPORTED, "rk_db_create: direct table needs sigma^k <= 2^31 slots");
+    if (mode != RK_TABLE_DIRECT && mode != RK_TABLE_HASH) return fail(RK_ERR_INVALID, "rk_db_create: bad table_mode %u", mode);
+
+    // ---- validate rows, lay out the row blob ----
+    std::vector<uint64_t> desc(n_keys);
+    uint64_t blob_bytes = 8;  // offset 0 is reserved so that a zero descriptor means "absent"
+    uint32_t max_len = 0;
+    for (uint64_t r = 0; r < n_keys; r++) {
+        uint64_t b = d->row_offsets[r], e = d->row_offsets[r + 1];
+        if (e < b) return fail(RK_ERR_INVALID, "rk_db_create: row_offsets not monotone at key %llu", (unsigned long long)r);
+        uint64_t len = e - b;
+        if (len == 0) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an empty row", (unsigned long long)r);
+        if (len >= (1ull << DESC_LEN_BITS) || len > d->n_branches)
+            return fail(RK_ERR_INVALID, "rk_db_create: row %llu has %llu entries (> n_branches)", (unsigned long long)r, (unsigned long long)len);
+        if (len > max_len) max_len = (uint32_t)len;
+        desc[r] = ((blob_bytes >> 3) << DESC_LEN_BITS) | len;
+        blob_bytes += row_bytes(len);
+    }
+    if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
+    std::vector<unsigned char> blob;
+    try { blob.assign(blob_bytes, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
+    {
+        std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
+        for (uint64_t r = 0; r < n_keys; r++) {
+            uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
+            unsigned char *p = blob.data() + ((desc[r] >> DESC_LEN_BITS) << 3);
+            uint16_t *bp = (uint16_t *)p;
+            float *sp = (float *)(p + (((len + 1) & ~1ull) << 1));
+            for (uint64_t i = 0; i < len; i++) {
+                uint16_t x = d->branch_ids[b + i];
+                float v = d->scores[b + i];
+                if (x >= d->n_branches) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u >= n_branches in row %llu", x, (unsigned long long)r);
+                if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
+                stamp[x] = (uint32_t)r;
+                if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
+                bp[i] = x;
+                sp[i] = v;
+            }
+        }
+    }
+
+    // ---- table ----
+    std::vector<uint64_t> table;  // direct: desc per dense index; hash: pairs {key+1, desc}
+    uint64_t slots = 0, hash_mask = 0;
+    auto code_ok = [&](uint64_t code, uint64_t &dense) -> bool {
+        if (bits == 2) {
+            if (d->k * 2 < 64 && (code >> (2 * d->k))) return false;
+            dense = code;
+            return true;
+        }
+        if (d->k * 5 < 64 && (code >> (5 * d->k))) return false;
+        uint64_t idx = 0, pw = 1;
+        for (uint32_t i = 0; i < d->k; i++) {
+            uint64_t dig = (code >> (5 * i)) & 31;
+            if (dig >= 20) return false;
+            idx += dig * pw;
+            pw *= 20;
+        }
+        dense = idx;
+        return true;
+    };
+    try {
+        if (mode == RK_TABLE_DIRECT) {
+            slots = space;
+            table.assign(slots, 0);
+            for (uint64_t r = 0; r < n_keys; r++) {
+                uint64_t dense;
+                if (!code_ok(d->key_codes[r], dense)) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an invalid k-mer code", (unsigned long long)r);
+                if (table[dense]) return fail(RK_ERR_INVALID, "rk_db_create: duplicate k-mer code at key %llu", (unsigned long long)r);
+                table[dense] = desc[r];
+            }
+        } else {
+            slots = 16;
+            while (slots < 2 * n_keys) slots <<= 1;
+            hash_mask = slots - 1;
+            table.assign(slots * 2, 0);
+            for (uint64_t r = 0; r < n_keys; r++) {
+                uint64_t dense, code = d->key_codes[r];
+                if (!code_ok(code, dense)) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an invalid k-mer code", (unsigned long long)r);
+                uint64_t h = host_mix64(code) & hash_mask;
+                while (table[2 * h]) {
+                    if (table[2 * h] == code + 1) return fail(RK_ERR_INVALID, "rk_db_create: duplicate k-mer code at key %llu", (unsigned long long)r);
+                    h = (h + 1) & hash_mask;
+                }
+                table[2 * h] = code + 1;
+                table[2 * h + 1] = desc[r];
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(RK_ERR_NOMEM, "rk_db_create: host OOM building the k-mer table");
+    }
+
+    // ---- upload ----
+    rk_db *db = new (std::nothrow) rk_db();
+    if (!db) return fail(RK_ERR_NOMEM, "rk_db_create: host OOM");
+    db->info.device = d->device;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+#define DB_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            int c_ = fail(e_ == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            rk_db_destroy(db);                                                                    \
+            return c_;                                                                            \
+        }                                                                                         \
+    } while (0)
+    DB_TRY(hipSetDevice(d->device));
+    hipDeviceProp_t prop;
+    DB_TRY(hipGetDeviceProperties(&prop, d->device));
+    db->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    db->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
+    DB_TRY(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
+    const size_t table_bytes = table.size() * sizeof(uint64_t);
+    DB_TRY(hipMalloc(&db->d_table, table_bytes ? table_bytes : 8));
+    DB_TRY(hipMalloc(&db->d_rows, blob_bytes));
+    DB_TRY(hipMalloc((void **)&db->d_alpha, 256 + 320 + 16));
+    if (table_bytes) DB_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
+    DB_TRY(hipMemcpy(db->d_rows, blob.data(), blob_bytes, hipMemcpyHostToDevice));
+    Alphabet A;
+    build_alphabet(d->alphabet, d->convert_uo != 0, A);
+    DB_TRY(hipMemcpy(db->d_alpha, A.table, 256, hipMemcpyHostToDevice));
+    DB_TRY(hipMemcpy(db->d_alpha + 256, A.alts, 320, hipMemcpyHostToDevice));
+    DB_TRY(hipMemcpy(db->d_alpha + 576, A.alt_count, 16, hipMemcpyHostToDevice));
+#undef DB_TRY
+
+    db->convert_uo = d->convert_uo;
+    db->info.alphabet = d->alphabet; db->info.k = d->k; db->info.n_branches = d->n_branches;
+    db->info.table_mode = mode; db->info.thr_log10 = d->thr_log10; db->info.thr = d->thr;
+    db->info.n_keys = n_keys; db->info.n_entries = n_entries; db->info.table_slots = slots;
+    db->info.table_bytes = table_bytes; db->info.rows_bytes = blob_bytes; db->info.bits_per_symbol = bits;
+    db->info.max_row_len = max_len;
+    db->view.direct = mode == RK_TABLE_DIRECT ? (const u64 *)db->d_table : nullptr;
+    db->view.slots = mode == RK_TABLE_HASH ? (const uint4 *)db->d_table : nullptr;
+    db->view.hash_mask = hash_mask;
+    db->view.rows = (const unsigned char *)db->d_rows;
+    db->view.k = d->k; db->view.bits = bits; db->view.n_branches = d->n_branches; db->view.alphabet = d->alphabet;
+    db->view.T = d->thr_log10; db->view.P = d->thr; db->view.convert_uo = d->convert_uo;
+    *out = db;
+    return RK_OK;
+}
+
+extern "C" int rk_db_get_info(const rk_db *db, rk_db_info *info) {
+    if (!db || !info) return fail(RK_ERR_INVALID, "rk_db_get_info: null argument");
+    *info = db->info;
+    return RK_OK;
+}
+
+extern "C" uint32_t rk_packed_words(const rk_db *db, uint32_t max_len) {
+    if (!db) return 0;
+    uint64_t bits = (uint64_t)max_len * db->info.bits_per_symbol;
+    uint32_t w = (uint32_t)((bits + 31) / 32);
+    return w ? w : 1;
+}
+
+extern "C" int rk_set_lanes_per_read(rk_db *db, uint32_t lanes) {
+    if (!db) return fail(RK_ERR_INVALID, "rk_set_lanes_per_read: null db");
+    if (lanes != 0 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64)
+        return fail(RK_ERR_INVALID, "rk_set_lanes_per_read: lanes must be 0 (auto), 8, 16, 32 or 64");
+    db->lanes_per_read = lanes;
+    return RK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch geometry
+// ------------------------------------------------------------------------------------------------
+struct Geometry {
+    uint32_t G, NG, s_stride, list_cap, kcap, pu;
+    size_t lds_per_wave;
+    uint32_t waves_per_cu;
+};
+
+static uint32_t probe_unroll(uint32_t G) { return G <= 16 ? 4 : (G == 32 ? 2 : 1); }
+
+static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) {
+    const uint32_t nb = db->info.n_branches;
+    const uint32_t s_stride = (nb + 1) & ~1u;
+    const size_t target = db->lds_per_cu / 8;  // aim for >= 8 waves per CU
+    auto bytes_for = [&](uint32_t G, uint32_t cap) { return (size_t)(64 / G) * ((size_t)s_stride * 4 + (size_t)cap * 8); };
+    uint32_t G = db->lanes_per_read;
+    if (G == 0) {
+        G = 64;
+        for (uint32_t cand : {16u, 32u, 64u}) {
+            if (cand < keep_at_most) continue;
+            if (bytes_for(cand, probe_unroll(cand) * cand) <= target) { G = cand; break; }
+        }
+    }
+    if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
+    const uint32_t NG = 64 / G, pu = probe_unroll(G);
+    const uint32_t min_cap = pu * G < 64 ? 64 : pu * G;
+    // list capacity: whatever is left of the per-wave LDS target, clamped to [min_cap, 256]
+    size_t per_group_target = target / NG;
+    uint32_t cap = min_cap;
+    if (per_group_target > (size_t)s_stride * 4 + (size_t)min_cap * 8) {
+        size_t c = (per_group_target - (size_t)s_stride * 4) / 8;
+        cap = (uint32_t)(c > 256 ? 256 : c);
+        if (cap < min_cap) cap = min_cap;
+    }
+    g.G = G; g.NG = NG; g.s_stride = s_stride; g.list_cap = cap; g.pu = pu;
+    g.kcap = keep_at_most <= 8 ? 8 : 16;
+    g.lds_per_wave = bytes_for(G, cap);
+    if (g.lds_per_wave > db->lds_per_cu)
+        return fail(RK_ERR_UNSUPPORTED, "n_branches=%u needs %zu B of LDS per read, more than one CU has (%zu B)", nb, g.lds_per_wave, db->lds_per_cu);
+    uint32_t w = (uint32_t)(db->lds_per_cu / g.lds_per_wave);
+    g.waves_per_cu = w > 32 ? 32 : w;
+    return RK_OK;
+}
+
+template <int G, int BITS, bool DIRECT, int KCAP>
+static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream, bool dry) {
+    constexpr int PU = G <= 16 ? 4 : (G == 32 ? 2 : 1);
+    constexpr int U = 8;
+    auto kern = place_packed_kernel<G, BITS, DIRECT, KCAP, U, PU>;
+    const uint32_t wpb = db->waves_per_block;
+    const size_t lds = g.lds_per_wave * wpb;
+    if (dry) return RK_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t n_tiles = (args.n_reads + g.NG - 1) / g.NG;
+    uint64_t blocks = (uint64_t)db->cu_count * ((g.waves_per_cu + wpb - 1) / wpb);
+    const uint64_t need = (n_tiles + wpb - 1) / wpb;
+    if (blocks > need) blocks = need;
+    if (blocks == 0) return RK_OK;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+    return RK_OK;
+}
+
+template <int G, int BITS, bool DIRECT>
+static int launch_k(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry) {
+    if (g.kcap == 8) return launch_variant<G, BITS, DIRECT, 8>(db, g, a, s, dry);
+    if constexpr (G >= 16) return launch_variant<G, BITS, DIRECT, 16>(db, g, a, s, dry);
+    else return fail(RK_ERR_INVALID, "keep_at_most > 8 needs lanes_per_read >= 16");
+}
+template <int G, int BITS>
+static int launch_t(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry) {
+    return db->info.table_mode == RK_TABLE_DIRECT ? launch_k<G, BITS, true>(db, g, a, s, dry) : launch_k<G, BITS, false>(db, g, a, s, dry);
+}
+template <int G>
+static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry) {
+    return db->info.bits_per_symbol == 2 ? launch_t<G, 2>(db, g, a, s, dry) : launch_t<G, 5>(db, g, a, s, dry);
+}
+static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry = false) {
+    switch (g.G) {
+    case 8: return launch_b<8>(db, g, a, s, dry);
+    case 16: return launch_b<16>(db, g, a, s, dry);
+    case 32: return launch_b<32>(db, g, a, s, dry);
+    default: return launch_b<64>(db, g, a, s, dry);
+    }
+}
+
+template <int BITS, bool DIRECT>
+static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, const AmbArgs &m, hipStream_t stream) {
+    const size_t lds = (size_t)args.s_stride * 12;
+    if (lds > db->lds_per_cu)
+        return fail(RK_ERR_UNSUPPORTED, "ambiguity path keeps 3 per-branch vectors in LDS: n_branches=%u needs %zu B > %zu B", db->info.n_branches, lds, db->lds_per_cu);
+    const uint64_t groups = (args.n_reads + 63) / 64;
+    uint64_t waves_cu = db->lds_per_cu / lds;
+    if (waves_cu > 32) waves_cu = 32;
+    uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
+    if (blocks > groups) blocks = groups;
+    if (!blocks) return RK_OK;
+    if (args.keep_at_most <= 8) {
+        auto kern = place_ascii_kernel<BITS, DIRECT, 8>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
+    } else {
+        auto kern = place_ascii_kernel<BITS, DIRECT, 16>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
+    }
+    HIP_TRY(hipGetLastError());
+    return RK_OK;
+}
+
+static int launch_ascii(const rk_db *db, const PlaceArgs &a, const AmbArgs &m, hipStream_t s) {
+    const bool direct = db->info.table_mode == RK_TABLE_DIRECT;
+    if (db->info.bits_per_symbol == 2) return direct ? launch_ascii_v<2, true>(db, a, m, s) : launch_ascii_v<2, false>(db, a, m, s);
+    return direct ? launch_ascii_v<5, true>(db, a, m, s) : launch_ascii_v<5, false>(db, a, m, s);
+}
+
+static int check_params(const rk_params *p) {
+    if (!p) return fail(RK_ERR_INVALID, "null rk_params");
+    if (p->keep_at_most < 1 || p->keep_at_most > 16) return fail(RK_ERR_INVALID, "keep_at_most=%u outside 1..16", p->keep_at_most);
+    if (p->amb_mode > RK_AMB_MAX) return fail(RK_ERR_INVALID, "amb_mode=%u invalid", p->amb_mode);
+    if (std::isnan(p->keep_factor) || std::isnan(p->ns_bound)) return fail(RK_ERR_INVALID, "NaN in rk_params");
+    return RK_OK;
+}
+
+extern "C" const char *rk_kernel_name(const rk_db *db) {
+    if (!db) return "";
+    Geometry g;
+    rk_db *m = const_cast<rk_db *>(db);
+    if (choose_geometry(db, 7, g) != RK_OK) return "";
+    char buf[160];
+    snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,KCAP=%u,U=8,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
+             g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : "HASH", g.kcap, g.pu,
+             g.lds_per_wave, g.list_cap, g.waves_per_cu);
+    m->kernel_name = buf;
+    return m->kernel_name.c_str();
+}
+
+// ------------------------------------------------------------------------------------------------
+// device entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int rk_pack_reads_device(rk_db *db, uint64_t n_reads, const uint8_t *d_seq_ascii, const uint64_t *d_seq_off,
+                                    uint32_t words_per_read, uint32_t *d_packed, uint32_t *d_lens, uint32_t *d_flags,
+                                    void *stream) {
+    if (!db || !d_seq_ascii || !d_seq_off || !d_packed || !d_lens || !d_flags || words_per_read == 0)
+        return fail(RK_ERR_INVALID, "rk_pack_reads_device: null/zero argument");
+    if (n_reads == 0) return RK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(db->info.device));
+    HIP_TRY(hipMemsetAsync(d_flags, 0, n_reads * sizeof(uint32_t), s));
+    const uint64_t total = n_reads * words_per_read;
+    uint64_t blocks = (total + 255) / 256;
+    const uint64_t maxb = (uint64_t)db->cu_count * 16;
+    if (blocks > maxb) blocks = maxb;
+    if (db->info.bits_per_symbol == 2)
+        hipLaunchKernelGGL(pack_reads_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, d_seq_ascii, (const u64 *)d_seq_off, (u64)n_reads,
+                           words_per_read, (const unsigned char *)db->d_alpha, db->info.k, d_packed, d_lens, d_flags);
+    else
+        hipLaunchKernelGGL(pack_reads_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, d_seq_ascii, (const u64 *)d_seq_off, (u64)n_reads,
+                           words_per_read, (const unsigned char *)db->d_alpha, db->info.k, d_packed, d_lens, d_flags);
+    HIP_TRY(hipGetLastError());
+    return RK_OK;
+}
+
+extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_reads, const uint32_t *d_packed,
+                                      uint32_t words_per_read, const uint32_t *d_lens, uint32_t fixed_len,
+                                      const uint32_t *d_flags_in, const uint8_t *d_seq_ascii, const uint64_t *d_seq_off,
+                                      const rk_result *d_out, void *stream) {
+    if (!db || !d_out) return fail(RK_ERR_INVALID, "rk_place_packed_device: null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_reads == 0) return RK_OK;
+    if (!d_packed || words_per_read == 0) return fail(RK_ERR_INVALID, "rk_place_packed_device: null packed reads");
+    if (!d_out->n_rows || !d_out->branch || !d_out->score || !d_out->lwr || !d_out->flags)
+        return fail(RK_ERR_INVALID, "rk_place_packed_device: null result array");
+    if (!d_lens && (uint64_t)fixed_len * db->info.bits_per_symbol > (uint64_t)words_per_read * 32)
+        return fail(RK_ERR_INVALID, "rk_place_packed_device: fixed_len=%u does not fit %u words", fixed_len, words_per_read);
+    Geometry g;
+    rc = choose_geometry(db, p->keep_at_most, g);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(db->info.device));
+    hipStream_t s = (hipStream_t)stream;
+    PlaceArgs a{};
+    a.db = db->view;
+    a.n_reads = n_reads;
+    a.packed = d_packed; a.words_per_read = words_per_read; a.lens = d_lens; a.fixed_len = fixed_len;
+    a.flags_in = d_flags_in;
+    const bool ascii = d_flags_in && d_seq_ascii && d_seq_off;
+    a.has_ascii = ascii ? 1u : 0u;
+    a.keep_at_most = p->keep_at_most; a.keep_factor = p->keep_factor; a.ns_bound = p->ns_bound;
+    a.o_nrows = d_out->n_rows; a.o_branch = d_out->branch; a.o_score = d_out->score; a.o_lwr = d_out->lwr; a.o_flags = d_out->flags;
+    a.s_stride = g.s_stride; a.list_cap = g.list_cap;
+    rc = launch_place(db, g, a, s);
+    if (rc) return rc;
+    if (ascii) {
+        AmbArgs m{};
+        m.ascii = d_seq_ascii; m.seq_off = (const u64 *)d_seq_off;
+        m.char_table = db->d_alpha; m.alt_table = db->d_alpha + 256; m.alt_count = db->d_alpha + 576;
+        m.amb_mode = p->amb_mode;
+        m.max_amb = (uint32_t)std::floor(std::pow((double)db->info.k, 1.0 / (double)db->info.alphabet));  // AmbigSequenceKnife.java:95
+        rc = launch_ascii(db, a, m, s);
+        if (rc) return rc;
+    }
+    return RK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-buffer entry point
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
+    template <class T> T *as() { return (T *)p; }
+};
+}  // namespace
+
+extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
+                              const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
+    if (!db || !out) return fail(RK_ERR_INVALID, "rk_place_batch: null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    rk_counters ct{};
+    if (n_reads == 0) { if (counters) *counters = ct; return RK_OK; }
+    if (!seq_ascii || !seq_off) return fail(RK_ERR_INVALID, "rk_place_batch: null reads");
+    if (!out->n_rows || !out->branch || !out->score || !out->lwr || !out->flags) return fail(RK_ERR_INVALID, "rk_place_batch: null result array");
+    for (uint64_t r = 0; r < n_reads; r++)
+        if (seq_off[r + 1] < seq_off[r]) return fail(RK_ERR_INVALID, "rk_place_batch: seq_off not monotone at read %llu", (unsigned long long)r);
+    HIP_TRY(hipSetDevice(db->info.device));
+    const uint32_t K = p->keep_at_most;
+    const uint64_t max_chunk_reads = 1ull << 20, max_chunk_bytes = 256ull << 20;
+    hipStream_t s = db->stream;
+    uint64_t r0 = 0;
+    while (r0 < n_reads) {
+        uint64_t r1 = r0, max_len = 0;
+        while (r1 < n_reads && r1 - r0 < max_chunk_reads && (seq_off[r1 + 1] - seq_off[r0] <= max_chunk_bytes || r1 == r0)) {
+            uint64_t L = seq_off[r1 + 1] - seq_off[r1];
+            if (L > max_len) max_len = L;
+            r1++;
+        }
+        const uint64_t n = r1 - r0, nbytes = seq_off[r1] - seq_off[r0];
+        if (max_len > 0x7FFFFFFFull / 8) return fail(RK_ERR_UNSUPPORTED, "rk_place_batch: read longer than 2^28 symbols");
+        const uint32_t wpr = rk_packed_words(db, (uint32_t)max_len);
+        std::vector<uint64_t> off(n + 1);
+        for (uint64_t i = 0; i <= n; i++) off[i] = seq_off[r0 + i] - seq_off[r0];
+        DevBuf d_ascii, d_off, d_packed, d_lens, d_flags, d_nrows, d_branch, d_score, d_lwr, d_oflags;
+        HIP_TRY(d_ascii.alloc(nbytes));
+        HIP_TRY(d_off.alloc((n + 1) * 8));
+        HIP_TRY(d_packed.alloc(n * wpr * 4));
+        HIP_TRY(d_lens.alloc(n * 4));
+        HIP_TRY(d_flags.alloc(n * 4));
+        HIP_TRY(d_nrows.alloc(n));
+        HIP_TRY(d_branch.alloc(n * K * 2));
+        HIP_TRY(d_score.alloc(n * K * 4));
+        HIP_TRY(d_lwr.alloc(n * K * 8));
+        HIP_TRY(d_oflags.alloc(n * 4));
+        if (nbytes) HIP_TRY(hipMemcpyAsync(d_ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        rc = rk_pack_reads_device(db, n, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), wpr, d_packed.as<uint32_t>(),
+                                  d_lens.as<uint32_t>(), d_flags.as<uint32_t>(), s);
+        if (rc) return rc;
+        rk_result dres{d_nrows.as<uint8_t>(), d_branch.as<uint16_t>(), d_score.as<float>(), d_lwr.as<double>(), d_oflags.as<uint32_t>()};
+        rc = rk_place_packed_device(db, p, n, d_packed.as<uint32_t>(), wpr, d_lens.as<uint32_t>(), 0, d_flags.as<uint32_t>(),
+                                    d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), &dres, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out->n_rows + r0, d_nrows.p, n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->branch + r0 * K, d_branch.p, n * K * 2, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->score + r0 * K, d_score.p, n * K * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->lwr + r0 * K, d_lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->flags + r0, d_oflags.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        r0 = r1;
+    }
+    for (uint64_t r = 0; r < n_reads; r++) {
+        uint32_t f = out->flags[r];
+        ct.reads++;
+        if (f & RK_FLAG_PLACED) ct.placed++; else ct.unplaced++;
+        if (f & RK_FLAG_BAD_CHAR) ct.bad_char++;
+        if (f & RK_FLAG_TOO_SHORT) ct.too_short++;
+        if (f & RK_FLAG_AMBIGUOUS) ct.ambiguous++;
+    }
+    if (counters) *counters = ct;
+    return RK_OK;
+}

@@ -1,0 +1,578 @@
+// rk_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the phylo-kmer placement hot path.
+//
+// What the reference does per read (src/core/algos/PlacementProcess.java:645-1075):
+//   knife (AmbigSequenceKnife.java:98-272) -> compressMer (DNAStatesShifted.java:115-143) -> hash lookup
+//   (CustomHash_v4_FastUtil81.java:146-153) -> S[x] accumulate (:719-735) -> top-K (:396-451) -> LWR (:974-1025).
+//
+// MI355X mapping (DESIGN.md section "Kernels"):
+//   * a wavefront (64 lanes) is split into 64/G lane groups; each group owns one read at a time and a private
+//     score vector S[n_branches] (f32 bit patterns) + a hit list of row descriptors, both in LDS;
+//   * probe phase: lane <-> k-mer position; the k-mer code is funnel-shifted out of the packed read in
+//     registers; one 8-byte descriptor gather per k-mer (direct table) or a linear probe over 16-byte slots
+//     (hash table); hits are compacted into the LDS list with a ballot + popcount;
+//   * accumulate phase: rows are applied strictly in k-mer order (bit parity with the reference's sequential
+//     float32 adds); inside a row (branches unique) the G lanes of the group each own one entry and do a plain
+//     LDS read-modify-write -- no atomics, LDS operations of a wave execute in program order;  row gathers are
+//     software-pipelined through a register ring of depth U so U row chunks are in flight per lane;
+//   * select phase: per-lane sorted insertion of packed 64-bit keys (ordered score bits << 32 | ~branch),
+//     K rounds of group arg-max, LWR in fp64 on the first K lanes; the scan also resets S for the next read.
+// No MFMA: this is a gather/accumulate bounded by the memory system, not a contraction.
+#include "rk_device.h"
+#include "../../include/rappas_place.h"
+
+namespace rk {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 ord_f32(float f) {  // monotone map float -> u32 (Float.compare order)
+    u32 u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(u32 o) {
+    u32 u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(u32 raw_score_bits, u32 branch) {
+    return ((u64)ord_f32(__uint_as_float(raw_score_bits)) << 32) | (u64)(0xFFFFu - branch);
+}
+__device__ __forceinline__ u64 shfl64(u64 v, int src, int width) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = __shfl(lo, src, width);
+    hi = __shfl(hi, src, width);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int m, int width) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = __shfl_xor(lo, m, width);
+    hi = __shfl_xor(hi, m, width);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_f64(double v, int src, int width) {
+    return __longlong_as_double((long long)shfl64((u64)__double_as_longlong(v), src, width));
+}
+// LDS data exchanged between lanes of ONE wave: DS operations of a wave execute in order, so only the
+// compiler has to be stopped from reordering / caching.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// k-mer code at symbol position j of a packed record (symbol i at bits [i*BITS, (i+1)*BITS) of the
+// little-endian bit string).  DNA: this integer IS the reference key (compressMer bytes little-endian,
+// DNAStatesShifted.java:115-143).  AA: sum state_i << 5i (compressMer = identity, AAStates.java:195-197).
+template <int BITS>
+__device__ __forceinline__ u64 extract_code(const u32 *rec, u32 words, u32 j, u32 k) {
+    u32 bit = j * BITS;
+    u32 wi = bit >> 5, sh = bit & 31;
+    u32 w0 = rec[wi];
+    u32 w1 = (wi + 1 < words) ? rec[wi + 1] : 0u;
+    u64 lo = ((u64)w1 << 32) | w0;
+    u64 code = lo >> sh;
+    if (BITS * 12 + 31 > 64) {  // AA with k >= 7 needs a third word
+        u32 nbits = k * BITS;
+        if (nbits + sh > 64) {
+            u32 w2 = (wi + 2 < words) ? rec[wi + 2] : 0u;
+            code |= (u64)w2 << (64 - sh);
+        }
+    }
+    u32 nbits = k * BITS;
+    return nbits >= 64 ? code : (code & ((1ull << nbits) - 1));
+}
+
+// dense index of a code in the direct table: DNA -> the code itself; AA -> base-20 number of its 5-bit digits
+template <int BITS>
+__device__ __forceinline__ u64 dense_index(u64 code, u32 k) {
+    if (BITS == 2) return code;
+    u64 idx = 0, pw = 1;
+    for (u32 i = 0; i < k; i++) {
+        idx += ((code >> (5 * i)) & 31) * pw;
+        pw *= 20;
+    }
+    return idx;
+}
+
+template <int BITS, bool DIRECT>
+__device__ __forceinline__ u64 lookup_desc(const DbView &db, u64 code) {
+    if (DIRECT) {
+        return db.direct[dense_index<BITS>(code, db.k)];
+    } else {
+        u64 h = mix64(code) & db.hash_mask;
+        const u64 want = code + 1;
+        while (true) {
+            uint4 s = db.slots[h];
+            u64 key = ((u64)s.y << 32) | s.x;
+            if (key == want) return ((u64)s.w << 32) | s.z;
+            if (key == 0) return 0;
+            h = (h + 1) & db.hash_mask;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate: row cursor + register ring
+// ------------------------------------------------------------------------------------------------
+struct Cursor {
+    int h;
+    u32 rlen, rpos;
+    u64 rbase;
+};
+
+template <int G>
+__device__ __forceinline__ void cursor_issue(Cursor &c, const u64 *list, int cnt, u32 li,
+                                             const unsigned char *rows, u32 &br, float &sc) {
+    if (c.rpos >= c.rlen) {
+        c.h++;
+        c.rpos = 0;
+        if (c.h < cnt) {
+            u64 d = list[c.h];
+            c.rlen = (u32)d & DESC_LEN_MASK;
+            c.rbase = (d >> DESC_LEN_BITS) << 3;
+        } else {
+            c.rlen = 0;
+        }
+    }
+    u32 e = c.rpos + li;
+    br = 0xFFFFu;
+    sc = 0.0f;
+    if (e < c.rlen) {
+        const unsigned char *p = rows + c.rbase;
+        br = ((const unsigned short *)p)[e];
+        sc = ((const float *)(p + (((c.rlen + 1) & ~1u) << 1)))[e];
+    }
+    c.rpos += G;
+}
+
+// S[x] update of PlacementProcess.java:726-733: first touch seeds fl(Q*T), then S = fl(S + fl(v - T)).
+__device__ __forceinline__ void apply_entry(u32 *S, u32 br, float sc, float QT, float T) {
+    if (br != 0xFFFFu) {
+        u32 old = S[br];
+        float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+        float d = sc - T;
+        float nw = base + d;
+        S[br] = __float_as_uint(nw);
+    }
+}
+
+template <int G, int U>
+__device__ __forceinline__ void accumulate_list(u32 *S, const u64 *list, int cnt, u32 li,
+                                                const unsigned char *rows, float QT, float T) {
+    Cursor c;
+    c.h = -1; c.rlen = 0; c.rpos = 0; c.rbase = 0;
+    u32 br[U];
+    float sc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) cursor_issue<G>(c, list, cnt, li, rows, br[u], sc[u]);
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            apply_entry(S, br[u], sc[u], QT, T);
+            cursor_issue<G>(c, list, cnt, li, rows, br[u], sc[u]);
+        }
+        if (!__any(c.h < cnt)) break;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) apply_entry(S, br[u], sc[u], QT, T);
+}
+
+// ------------------------------------------------------------------------------------------------
+// select: top-K + LWR + output (A8/A9: PlacementProcess.java:396-451, :974-1025)
+// ------------------------------------------------------------------------------------------------
+template <int KCAP>
+__device__ __forceinline__ void topk_insert(u64 (&t)[KCAP], u64 key) {
+#pragma unroll
+    for (int i = 0; i < KCAP; i++) {
+        bool bigger = key > t[i];
+        u64 tmp = bigger ? t[i] : key;
+        t[i] = bigger ? key : t[i];
+        key = tmp;
+    }
+}
+
+// Scans S[0..nb) with the G lanes of the group, resets it to UNTOUCHED, leaves rank-r winner in lane r (r < K).
+// Returns numBest (uniform in the group); win_key valid in lanes li < numBest.
+template <int G, int KCAP>
+__device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, int K, u64 &win_key) {
+    u64 t[KCAP];
+#pragma unroll
+    for (int i = 0; i < KCAP; i++) t[i] = 0;
+    for (u32 i = li; i < nb; i += G) {
+        u32 raw = S[i];
+        if (raw != S_UNTOUCHED) {
+            S[i] = S_UNTOUCHED;
+            u64 key = make_key(raw, i);
+            if (key > t[KCAP - 1]) topk_insert<KCAP>(t, key);
+        }
+    }
+    win_key = 0;
+    int num = 0;
+    for (int r = 0; r < K; r++) {
+        u64 m = t[0];
+#pragma unroll
+        for (int s = 1; s < G; s <<= 1) {
+            u64 o = shfl_xor64(m, s, G);
+            m = o > m ? o : m;
+        }
+        if (m == 0) break;  // group-uniform
+        num++;
+        if (t[0] == m) {  // unique winner (branch ids are unique) pops its head
+#pragma unroll
+            for (int i = 0; i < KCAP - 1; i++) t[i] = t[i + 1];
+            t[KCAP - 1] = 0;
+        }
+        if ((int)li == r) win_key = m;
+    }
+    return num;
+}
+
+// LWR + keep-factor + output rows for one read.  Called by all lanes of the group (li = lane in group).
+// Requires G >= keep_at_most.
+template <int G>
+__device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 li, int numBest, u64 win_key,
+                                                u32 flags) {
+    const int K = (int)a.keep_at_most;
+    float score = unord_f32((u32)(win_key >> 32));
+    u32 branch = 0xFFFFu - (u32)(win_key & 0xFFFFu);
+    int n_rows = 0;
+    double lwr = 0.0;
+    if (numBest > 0) {
+        flags |= RK_FLAG_PLACED;
+        float best = __shfl(score, 0, G);
+        float lowest = __shfl(score, numBest - 1, G);
+        // computeWeightRatioShift (PlacementProcess.java:384-390); `lowest` starts at 0.0f in :413 and every
+        // score is < 0 whenever the shift matters, so min(0, lowest) <= -308 <=> lowest <= -308.
+        float lowest0 = lowest < 0.0f ? lowest : 0.0f;
+        float shift = (-308.0f >= lowest0) ? best : 0.0f;
+        bool mine = (int)li < numBest;
+        // :441-448  sum_{ascending} pow(10, (double)(float)(score - shift));  (:418 sums in heap order when
+        // shift == 0 -- same terms, order differs only in the last ulp of a double)
+        float d32 = score - shift;
+        double term = mine ? pow(10.0, (double)d32) : 0.0;
+        double sum = 0.0;
+        for (int q = numBest - 1; q >= 0; q--) sum += shfl_f64(term, q, G);
+        float shift2 = (-308.0f >= lowest) ? best : 0.0f;  // :978-980 uses the true minimum
+        double ratio = mine ? pow(10.0, (double)score - (double)shift2) / sum : 0.0;  // :392-394
+        double best_ratio = shfl_f64(ratio, 0, G);
+        bool fail = mine && li > 0 && (ratio < best_ratio * (double)a.keep_factor);  // :998-1000
+        u64 fb = __ballot(fail);
+        u32 lane = threadIdx.x & 63;
+        u32 gshift = lane - li;  // first lane of the group
+        u64 gm = (G == 64) ? ~0ull : (((1ull << G) - 1) << gshift);
+        u64 failm = (fb & gm) >> gshift;
+        failm |= 1ull << numBest;
+        n_rows = __builtin_ctzll(failm);
+        lwr = ratio;
+        if (!(best >= a.ns_bound)) {  // :974
+            n_rows = 0;
+            flags |= RK_FLAG_BELOW_NSBOUND;
+        }
+    }
+    if ((int)li < K) {
+        bool on = (int)li < n_rows;
+        a.o_branch[r * K + li] = on ? (unsigned short)branch : (unsigned short)0xFFFFu;
+        a.o_score[r * K + li] = on ? score : -INFINITY;
+        a.o_lwr[r * K + li] = on ? lwr : 0.0;
+    }
+    if (li == 0) {
+        a.o_nrows[r] = (unsigned char)n_rows;
+        a.o_flags[r] = flags;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main placement kernel: reads packed 2-bit / 5-bit, no ambiguity characters
+// ------------------------------------------------------------------------------------------------
+template <int G, int BITS, bool DIRECT, int KCAP, int U, int PU>
+__global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
+    constexpr int NG = 64 / G;
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = threadIdx.x >> 6;
+    const u32 waves_per_block = blockDim.x >> 6;
+    const u32 gi = lane / G, li = lane % G;
+    const u32 wave_words = NG * (a.s_stride + 2 * a.list_cap);
+    u32 *wbase = lds + wave * wave_words;
+    u32 *S = wbase + gi * a.s_stride;
+    u64 *list = (u64 *)(wbase + NG * a.s_stride) + gi * a.list_cap;
+    const u32 nb = a.db.n_branches;
+    const u32 k = a.db.k;
+    const float T = a.db.T;
+    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    const int cap = (int)a.list_cap;
+
+    for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
+    wave_lds_fence();
+
+    const u64 n_tiles = (a.n_reads + NG - 1) / NG;
+    const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
+    const u64 wave_count = (u64)gridDim.x * waves_per_block;
+    for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const u64 r = tile * NG + gi;
+        const bool have = r < a.n_reads;
+        u32 R = 0, fin = 0;
+        if (have) {
+            R = a.lens ? a.lens[r] : a.fixed_len;
+            fin = a.flags_in ? a.flags_in[r] : 0u;
+        }
+        u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        if (R < k) flags |= RK_FLAG_TOO_SHORT;
+        // Q = sk.getMerCount() (AmbigSequenceKnife.java:191)
+        const u32 Q = (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
+        const float QT = (float)(int)Q * T;  // int * float (PlacementProcess.java:728)
+        const u32 *rec = a.packed + r * a.words_per_read;
+
+        u32 pos = 0;
+        while (__any(pos < Q)) {
+            // ---- probe: fill the hit list (k-mer order preserved by the rank compaction) ----
+            int cnt = 0;
+            while (true) {
+                const bool more = (pos < Q) && (cnt + PU * G <= cap);
+                if (!__any(more)) break;
+                u64 desc[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    desc[u] = 0;
+                    u32 j = pos + u * G + li;
+                    if (more && j < Q) desc[u] = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                }
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    bool hit = ((u32)desc[u] & DESC_LEN_MASK) != 0;
+                    u64 b = __ballot(hit);
+                    u32 sub = (u32)((b >> (gi * G)) & gmask);
+                    if (G == 64) {
+                        u64 below = b & ((1ull << li) - 1);
+                        if (hit) list[cnt + __builtin_popcountll(below)] = desc[u];
+                        cnt += __builtin_popcountll(b);
+                    } else {
+                        if (hit) list[cnt + __builtin_popcount(sub & ((1u << li) - 1))] = desc[u];
+                        cnt += __builtin_popcount(sub);
+                    }
+                }
+                if (more) pos += PU * G;
+            }
+            if constexpr (PU > 1) {
+                while (true) {  // tail passes, one group-width at a time
+                    const bool more = (pos < Q) && (cnt + G <= cap);
+                    if (!__any(more)) break;
+                    u64 d = 0;
+                    u32 j = pos + li;
+                    if (more && j < Q) d = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                    bool hit = ((u32)d & DESC_LEN_MASK) != 0;
+                    u64 b = __ballot(hit);
+                    u32 sub = (u32)((b >> (gi * G)) & gmask);
+                    if (hit) list[cnt + __builtin_popcount(sub & ((1u << li) - 1))] = d;
+                    cnt += __builtin_popcount(sub);
+                    if (more) pos += G;
+                }
+            }
+            wave_lds_fence();
+            // ---- accumulate in k-mer order ----
+            if (__any(cnt > 0)) accumulate_list<G, U>(S, list, cnt, li, a.db.rows, QT, T);
+            wave_lds_fence();
+        }
+
+        // ---- select + weigh + store (also resets S) ----
+        u64 win_key;
+        int numBest = select_topk<G, KCAP>(S, nb, li, (int)a.keep_at_most, win_key);
+        wave_lds_fence();
+        const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+        if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ASCII kernel for reads that contain ambiguity characters (one wave per read, sequential k-mers).
+// A1/A2/A7: AmbigSequenceKnife.java:98-272, PlacementProcess.java:1129-1236.
+// ------------------------------------------------------------------------------------------------
+struct AmbArgs {
+    const unsigned char *ascii;
+    const u64 *seq_off;
+    const unsigned char *char_table;  // [256] state | 0x80|class | 0xFF
+    const unsigned char *alt_table;   // [16][20] alternatives per class
+    const unsigned char *alt_count;   // [16]
+    u32 amb_mode;
+    u32 max_amb;
+};
+
+template <int BITS, bool DIRECT>
+__device__ __forceinline__ void amb_apply_plain(const DbView &db, u32 *S, u64 desc, u32 lane, float QT, float T) {
+    u32 len = (u32)desc & DESC_LEN_MASK;
+    const unsigned char *p = db.rows + ((desc >> DESC_LEN_BITS) << 3);
+    const unsigned short *bp = (const unsigned short *)p;
+    const float *sp = (const float *)(p + (((len + 1) & ~1u) << 1));
+    for (u32 e = lane; e < len; e += 64) apply_entry(S, bp[e], sp[e], QT, T);
+}
+
+template <int BITS, bool DIRECT, int KCAP>
+__global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m) {
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63;
+    const u32 nb = a.db.n_branches;
+    u32 *S = lds;
+    float *Samb = (float *)(lds + a.s_stride);
+    u32 *Camb = lds + 2 * a.s_stride;
+    const u32 k = a.db.k;
+    const float T = a.db.T, P = a.db.P;
+    for (u32 i = lane; i < a.s_stride; i += 64) { S[i] = S_UNTOUCHED; Samb[i] = 0.0f; Camb[i] = 0; }
+    wave_lds_fence();
+    const u64 kmask = (k * BITS >= 64) ? ~0ull : ((1ull << (k * BITS)) - 1);
+
+    for (u64 r0 = (u64)blockIdx.x * 64; r0 < a.n_reads; r0 += (u64)gridDim.x * 64) {
+        // each lane inspects one read's flag; the wave then serves the flagged ones in turn
+        u64 rr = r0 + lane;
+        u32 f = (rr < a.n_reads) ? a.flags_in[rr] : 0u;
+        bool want = (f & RK_FLAG_AMBIGUOUS) && !(f & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG));
+        u64 todo = __ballot(want);
+        while (todo) {
+            int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const u64 r = r0 + src;
+            const unsigned char *s = m.ascii + m.seq_off[r];
+            const u32 R = (u32)(m.seq_off[r + 1] - m.seq_off[r]);
+            u32 flags = RK_FLAG_AMBIGUOUS;
+            if (R < k) flags |= RK_FLAG_TOO_SHORT;
+            const u32 Q = R >= k ? R - k + 1 : 0;
+            const float QT = (float)(int)Q * T;
+            // rolling window state (identical in every lane)
+            u64 code = 0;   // ambiguous positions contribute state 0
+            u32 ambmask = 0;  // bit i <=> window position i is ambiguous
+            for (u32 i = 0; i + 1 < k && i < R; i++) {
+                u32 c = m.char_table[s[i]];
+                u32 st = (c & 0x80) ? 0u : c;
+                code |= (u64)st << (BITS * i);
+                ambmask |= ((c >> 7) & 1u) << i;
+            }
+            for (u32 j = 0; j < Q; j++) {
+                {
+                    u32 c = m.char_table[s[j + k - 1]];
+                    u32 st = (c & 0x80) ? 0u : c;
+                    code |= (u64)st << (BITS * (k - 1));
+                    ambmask |= ((c >> 7) & 1u) << (k - 1);
+                }
+                const u32 namb = __builtin_popcount(ambmask);
+                if (namb == 0) {
+                    u64 desc = lookup_desc<BITS, DIRECT>(a.db, code);
+                    if ((u32)desc & DESC_LEN_MASK) amb_apply_plain<BITS, DIRECT>(a.db, S, desc, lane, QT, T);
+                } else if (namb <= m.max_amb && namb == 1 && m.amb_mode != RK_AMB_SKIP) {
+                    const u32 p = __builtin_ctz(ambmask);
+                    const u32 cls = m.char_table[s[j + p]] & 0x7F;
+                    const u32 W = m.alt_count[cls];
+                    // pass 1: gather alternatives into Samb / Camb (sequential over alternatives)
+                    for (u32 w = 0; w < W; w++) {
+                        u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
+                        u64 desc = lookup_desc<BITS, DIRECT>(a.db, cw);
+                        u32 len = (u32)desc & DESC_LEN_MASK;
+                        if (!len) continue;
+                        const unsigned char *pr = a.db.rows + ((desc >> DESC_LEN_BITS) << 3);
+                        const unsigned short *bp = (const unsigned short *)pr;
+                        const float *sp = (const float *)(pr + (((len + 1) & ~1u) << 1));
+                        for (u32 e = lane; e < len; e += 64) {
+                            u32 x = bp[e];
+                            float v = sp[e];
+                            u32 c = Camb[x];
+                            Camb[x] = c + 1;
+                            if (m.amb_mode == RK_AMB_MEAN) {
+                                // S_amb[x] += Math.pow(10, v)  (float += double, :1155)
+                                Samb[x] = (float)((double)Samb[x] + pow(10.0, (double)v));
+                            } else {
+                                float cur = Samb[x];
+                                Samb[x] = (c == 0 || v > cur) ? v : cur;  // :1212-1217
+                            }
+                        }
+                        wave_lds_fence();
+                    }
+                    // pass 2: fold into S; the first alternative row that lists x does it (per-branch updates
+                    // are independent, so the L_amb visiting order does not change any S[x])
+                    for (u32 w = 0; w < W; w++) {
+                        u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
+                        u64 desc = lookup_desc<BITS, DIRECT>(a.db, cw);
+                        u32 len = (u32)desc & DESC_LEN_MASK;
+                        if (!len) continue;
+                        const unsigned short *bp = (const unsigned short *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
+                        for (u32 e = lane; e < len; e += 64) {
+                            u32 x = bp[e];
+                            u32 c = Camb[x];
+                            if (c != 0) {
+                                u32 old = S[x];
+                                float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+                                float nw;
+                                if (m.amb_mode == RK_AMB_MEAN) {
+                                    float missing = (float)(int)(W - c);  // :1168, all float32
+                                    float pad = missing * P;
+                                    float tot = Samb[x] + pad;
+                                    float avg = tot / (float)(int)W;
+                                    nw = (float)((double)base + (log10((double)avg) - (double)T));  // :1169
+                                } else {
+                                    float d = Samb[x] - T;  // :1230
+                                    nw = base + d;
+                                }
+                                S[x] = __float_as_uint(nw);
+                                Camb[x] = 0;
+                                Samb[x] = 0.0f;
+                            }
+                        }
+                        wave_lds_fence();
+                    }
+                }
+                // slide
+                code >>= BITS;
+                ambmask >>= 1;
+            }
+            wave_lds_fence();
+            u64 win_key;
+            int numBest = select_topk<64, KCAP>(S, nb, lane, (int)a.keep_at_most, win_key);
+            wave_lds_fence();
+            weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
+            (void)kmask;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack kernel: ASCII -> packed records + lens + flags (AmbigSequenceKnife.java:103-130 char -> state)
+// one thread per output word
+// ------------------------------------------------------------------------------------------------
+template <int BITS>
+__global__ void __launch_bounds__(256) pack_reads_kernel(const unsigned char *ascii, const u64 *seq_off, u64 n_reads,
+                                                          u32 words_per_read, const unsigned char *char_table, u32 k,
+                                                          u32 *packed, u32 *lens, u32 *flags) {
+    __shared__ unsigned char tab[256];
+    tab[threadIdx.x & 255] = char_table[threadIdx.x & 255];
+    __syncthreads();
+    const u64 total = n_reads * words_per_read;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 r = t / words_per_read;
+        const u32 w = (u32)(t - r * words_per_read);
+        const u64 o0 = seq_off[r];
+        const u64 Rfull = seq_off[r + 1] - o0;
+        const u32 cap_syms = (words_per_read * 32u) / BITS;
+        const u32 R = Rfull > cap_syms ? cap_syms : (u32)Rfull;
+        u32 fl = 0;
+        if (w == 0) {
+            lens[r] = R;
+            if (Rfull > cap_syms) fl |= RK_FLAG_TOO_LONG;
+            if (R < k) fl |= RK_FLAG_TOO_SHORT;
+        }
+        // symbols overlapping bits [32w, 32w+32)
+        const u32 s_lo = (32u * w) / BITS;
+        u32 s_hi = (32u * w + 31u) / BITS;  // inclusive
+        u64 acc = 0;                        // bits relative to 32w - (BITS-1) .. keep simple with signed shifts
+        for (u32 sidx = s_lo; sidx <= s_hi; sidx++) {
+            if (sidx >= R) break;
+            u32 c = tab[ascii[o0 + sidx]];
+            u32 st = c;
+            if (c == 0xFF) { fl |= RK_FLAG_BAD_CHAR; st = 0; }
+            else if (c & 0x80) { fl |= RK_FLAG_AMBIGUOUS; st = 0; }
+            int shift = (int)(sidx * BITS) - (int)(32u * w);
+            if (shift >= 0) acc |= (u64)st << shift;
+            else acc |= (u64)st >> (-shift);
+        }
+        packed[t] = (u32)acc;
+        if (fl) atomicOr(&flags[r], fl);
+    }
+}
+
+}  // namespace rk

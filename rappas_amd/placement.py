@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's placement interface, over the C ABI (include/rappas_place.h).
+
+Names follow the reference: `PhyloKmerDB` stands where `session.hash` (CustomHash_v4_FastUtil81) plus the session
+scalars stand (src/main_v2/SessionNext_v2.java:43-66); `PlacementProcess.processQueries` takes the arguments of
+src/core/algos/PlacementProcess.java:471-483 that reach the hot path (keepAtMost, keepFactor, treatAmbiguities,
+treatAmbiguitiesWithMax) and returns, per read, what :974-1025 turns into jplace rows.
+No compute happens in Python and nothing here falls back to a CPU implementation.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import (RK_ALPHABET_AA, RK_ALPHABET_DNA, RK_AMB_MAX, RK_AMB_MEAN, RK_AMB_SKIP, RK_TABLE_AUTO,
+                   RK_TABLE_DIRECT, RK_TABLE_HASH, rk_counters, rk_db_desc, rk_db_info, rk_params, rk_result)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Placements:
+    """Rows best -> worse per read; unused rows are branch 0xFFFF / score -inf / lwr 0."""
+    n_rows: np.ndarray   # u8  [n]
+    branch: np.ndarray   # u16 [n, K]
+    score: np.ndarray    # f32 [n, K]
+    lwr: np.ndarray      # f64 [n, K]
+    flags: np.ndarray    # u32 [n]
+    counters: dict
+
+
+class PhyloKmerDB:
+    """Phylo-kmer DB resident in one GPU's HBM (open-addressed / direct table + CSR rows)."""
+
+    def __init__(self, alphabet, k, n_branches, thr_log10, thr, key_codes, row_offsets, branch_ids, scores,
+                 device=0, table_mode=RK_TABLE_AUTO, convert_uo=False):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        key_codes = np.ascontiguousarray(key_codes, dtype=np.uint64)
+        row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+        branch_ids = np.ascontiguousarray(branch_ids, dtype=np.uint16)
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        if row_offsets.shape[0] != key_codes.shape[0] + 1:
+            raise ValueError("row_offsets must have n_keys+1 entries")
+        if key_codes.shape[0] and int(row_offsets[-1]) != branch_ids.shape[0]:
+            raise ValueError("row_offsets[-1] must equal len(branch_ids)")
+        if branch_ids.shape[0] != scores.shape[0]:
+            raise ValueError("branch_ids and scores differ in length")
+        d = rk_db_desc(alphabet, int(bool(convert_uo)), k, n_branches, float(thr_log10), float(thr),
+                       key_codes.shape[0], _ptr(key_codes), _ptr(row_offsets), _ptr(branch_ids), _ptr(scores),
+                       device, table_mode)
+        _lib.check(self._lib.rk_db_create(C.byref(d), C.byref(self._h)))
+        info = rk_db_info()
+        _lib.check(self._lib.rk_db_get_info(self._h, C.byref(info)))
+        self.info = info
+
+    @classmethod
+    def from_synth(cls, db, **kw):
+        return cls(db.alphabet, db.k, db.n_branches, db.thr_log10, db.thr, db.key_codes, db.row_offsets,
+                   db.branch_ids, db.scores, **kw)
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("PhyloKmerDB is closed")
+        return self._h
+
+    def set_lanes_per_read(self, lanes):
+        _lib.check(self._lib.rk_set_lanes_per_read(self.handle, lanes))
+
+    def kernel_name(self):
+        return self._lib.rk_kernel_name(self.handle).decode()
+
+    def packed_words(self, max_len):
+        return int(self._lib.rk_packed_words(self.handle, max_len))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rk_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PlacementProcess:
+    """Mirror of core.algos.PlacementProcess for the hot path."""
+
+    def __init__(self, db, ns_bound=float("-inf")):
+        self.db = db
+        self.ns_bound = ns_bound  # PlacementProcess(session, nsBound, queryLimit) (Main_PLACEMENT_v07.java:248-253)
+        self._lib = _lib.load()
+
+    def _params(self, keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax):
+        amb = RK_AMB_SKIP if not treatAmbiguities else (RK_AMB_MAX if treatAmbiguitiesWithMax else RK_AMB_MEAN)
+        return rk_params(keepAtMost, keepFactor, amb, self.ns_bound)
+
+    def processQueries(self, seq, seq_off, keepAtMost=7, keepFactor=0.01, treatAmbiguities=True,
+                       treatAmbiguitiesWithMax=False):
+        """seq: uint8 ASCII of all reads concatenated (no gap stripping, as FASTAPointer(q,false) delivers them);
+        seq_off: uint64 [n+1].  Defaults = src/main_v2/ArgumentsParser_v2.java:87-91."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        n = seq_off.shape[0] - 1
+        K = keepAtMost
+        out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
+                         np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
+        res = rk_result(_ptr(out.n_rows), _ptr(out.branch), _ptr(out.score), _ptr(out.lwr), _ptr(out.flags))
+        p = self._params(keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax)
+        ct = rk_counters()
+        _lib.check(self._lib.rk_place_batch(self.db.handle, C.byref(p), n, _ptr(seq), _ptr(seq_off), C.byref(res),
+                                            C.byref(ct)))
+        out.counters = {f: getattr(ct, f) for f, _ in rk_counters._fields_}
+        return out
+
+    # ---- device-resident variant (torch tensors only carry the memory and the stream) ----
+    def place_packed(self, packed, fixed_len=0, lens=None, flags_in=None, seq_ascii=None, seq_off=None, out=None,
+                     keepAtMost=7, keepFactor=0.01, treatAmbiguities=True, treatAmbiguitiesWithMax=False,
+                     stream=None):
+        import torch
+        n, wpr = packed.shape
+        dev = packed.device
+        K = keepAtMost
+        if out is None:
+            out = dict(n_rows=torch.empty(n, dtype=torch.uint8, device=dev),
+                       branch=torch.empty((n, K), dtype=torch.int16, device=dev),
+                       score=torch.empty((n, K), dtype=torch.float32, device=dev),
+                       lwr=torch.empty((n, K), dtype=torch.float64, device=dev),
+                       flags=torch.empty(n, dtype=torch.int32, device=dev))
+        res = rk_result(out["n_rows"].data_ptr(), out["branch"].data_ptr(), out["score"].data_ptr(),
+                        out["lwr"].data_ptr(), out["flags"].data_ptr())
+        p = self._params(keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        dp = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.rk_place_packed_device(self.db.handle, C.byref(p), n, packed.data_ptr(), wpr, dp(lens),
+                                                    fixed_len, dp(flags_in), dp(seq_ascii), dp(seq_off),
+                                                    C.byref(res), C.c_void_p(st)))
+        return out
+
+    def pack_reads(self, seq_ascii, seq_off, max_len, stream=None):
+        import torch
+        n = seq_off.shape[0] - 1
+        dev = seq_ascii.device
+        wpr = self.db.packed_words(max_len)
+        packed = torch.empty((n, wpr), dtype=torch.int32, device=dev)
+        lens = torch.empty(n, dtype=torch.int32, device=dev)
+        flags = torch.empty(n, dtype=torch.int32, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._lib.rk_pack_reads_device(self.db.handle, n, seq_ascii.data_ptr(), seq_off.data_ptr(), wpr,
+                                                  packed.data_ptr(), lens.data_ptr(), flags.data_ptr(),
+                                                  C.c_void_p(st)))
+        return packed, lens, flags

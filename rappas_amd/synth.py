@@ -1,0 +1,158 @@
+"""Seeded synthetic phylo-kmer DBs and reads (BASELINE.md section 4 / SURVEY.md section 8(d)).
+
+Only shapes matter to the kernels: n_branches = 2*leaves-1 (branch id 0 = root never carries entries),
+keys = random subset of the k-mer code space, row length ~ geometric with the requested mean, branch ids a
+contiguous window of the pre-order id range, scores v = T*u with u~U(0,1) float32 so that T <= v <= 0
+(what the reference's DB build can emit, src/core/algos/WordExplorer_v3.java:120-137).
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+DNA_LETTERS = np.frombuffer(b"ATCG", dtype=np.uint8)                    # state order of DNAStatesShifted.java:33
+AA_LETTERS = np.frombuffer(b"RHKDESTNQCGPAILMFWYV", dtype=np.uint8)     # AAStates.java:23-28
+
+CONFIGS = {
+    # name: (alphabet, k, leaves, n_keys, n_entries, read_len, n_reads)
+    "C1": (4, 8, 50, 49_152, 500_000, 150, 1_000),
+    "C2": (4, 10, 500, 786_432, 10_000_000, 150, 10_000_000),
+    "C4": (20, 5, 200, 320_000, 3_200_000, 100, 1_000_000),
+    "C5mini": (4, 12, 10_000, 1_048_576, 50_000_000, 250, 100_000),  # C5's tree/k at a DB size one test can hold
+}
+
+
+def thresholds(omega, n_states, k):
+    """float32 pair (PPStarThreshold, log10) as src/main_v2/Main_DBBUILD_3.java:165-166 computes it."""
+    ratio = np.float32(omega) / np.float32(n_states)
+    p = np.float32(math.pow(0.0 + float(ratio), k))
+    t = np.float32(math.log10(float(p)))
+    return p, t
+
+
+@dataclass
+class SynthDB:
+    alphabet: int
+    k: int
+    n_branches: int
+    thr: np.float32
+    thr_log10: np.float32
+    key_codes: np.ndarray    # u64 [n_keys]
+    row_offsets: np.ndarray  # u64 [n_keys+1]
+    branch_ids: np.ndarray   # u16 [n_entries]
+    scores: np.ndarray       # f32 [n_entries]
+    seed: int = 0
+
+    @property
+    def n_keys(self):
+        return int(self.key_codes.shape[0])
+
+    @property
+    def n_entries(self):
+        return int(self.branch_ids.shape[0])
+
+    @property
+    def bits(self):
+        return 2 if self.alphabet == 4 else 5
+
+
+def dense_to_code(alphabet, k, dense):
+    """dense index in [0, sigma^k) -> key code (DNA: identical; AA: base-20 digits repacked 5 bits each)."""
+    dense = np.asarray(dense, dtype=np.uint64)
+    if alphabet == 4:
+        return dense
+    code = np.zeros_like(dense)
+    rem = dense.copy()
+    for i in range(k):
+        code |= (rem % np.uint64(20)) << np.uint64(5 * i)
+        rem //= np.uint64(20)
+    return code
+
+
+def make_db(alphabet, k, n_branches, n_keys, n_entries, seed=42, omega=1.5, sort_keys=False):
+    rng = np.random.default_rng(seed)
+    space = alphabet ** k
+    n_keys = min(n_keys, space)
+    dense = rng.choice(space, size=n_keys, replace=False) if n_keys < space else rng.permutation(space)
+    if sort_keys:
+        dense = np.sort(dense)
+    key_codes = dense_to_code(alphabet, k, dense.astype(np.uint64))
+    mean = max(1.0, n_entries / max(1, n_keys))
+    lens = rng.geometric(1.0 / mean, size=n_keys).astype(np.int64)  # support {1,2,...}, mean `mean`
+    np.minimum(lens, max(1, n_branches - 1), out=lens)
+    row_offsets = np.zeros(n_keys + 1, dtype=np.uint64)
+    np.cumsum(lens, out=row_offsets[1:])
+    total = int(row_offsets[-1])
+    # contiguous window [b0, b0+len) inside [1, n_branches)
+    hi = np.maximum(1, n_branches - lens)  # b0 in [1, hi]
+    b0 = 1 + (rng.random(n_keys) * hi).astype(np.int64)
+    np.minimum(b0, hi, out=b0)
+    if n_branches == 1:
+        b0[:] = 0
+    within = np.arange(total, dtype=np.int64) - np.repeat(row_offsets[:-1].astype(np.int64), lens)
+    branch_ids = (np.repeat(b0, lens) + within).astype(np.uint16)
+    thr, thr_log10 = thresholds(omega, alphabet, k)
+    scores = (thr_log10 * rng.random(total, dtype=np.float32)).astype(np.float32)
+    return SynthDB(alphabet, k, n_branches, thr, thr_log10, key_codes, row_offsets, branch_ids, scores, seed)
+
+
+def make_config_db(name, seed=42, scale=1.0):
+    alphabet, k, leaves, n_keys, n_entries, _, _ = CONFIGS[name]
+    return make_db(alphabet, k, 2 * leaves - 1, int(n_keys * scale) if scale != 1.0 else n_keys,
+                   int(n_entries * scale), seed=seed)
+
+
+def make_reads(alphabet, n_reads, length, seed=1, amb_rate=0.0, bad_rate=0.0, var_len=0):
+    """ASCII reads, uniform i.i.d. over the unambiguous alphabet (seed 1 like RandomSeqGenerator.java:20-21).
+
+    amb_rate: per-symbol probability of an ambiguity character; bad_rate: per-read probability of one
+    unsupported character; var_len: lengths uniform in [length-var_len, length].
+    Returns (seq uint8 [total], off uint64 [n_reads+1]).
+    """
+    rng = np.random.default_rng(seed)
+    letters = DNA_LETTERS if alphabet == 4 else AA_LETTERS
+    if var_len:
+        lens = rng.integers(max(0, length - var_len), length + 1, size=n_reads).astype(np.uint64)
+    else:
+        lens = np.full(n_reads, length, dtype=np.uint64)
+    off = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    total = int(off[-1])
+    seq = letters[rng.integers(0, len(letters), size=total)]
+    if amb_rate > 0:
+        amb = np.frombuffer(b"NRYSWKMBDHVn-." if alphabet == 4 else b"XBZJ*-x", dtype=np.uint8)
+        m = rng.random(total) < amb_rate
+        seq = seq.copy()
+        seq[m] = amb[rng.integers(0, len(amb), size=int(m.sum()))]
+    if bad_rate > 0 and n_reads:
+        seq = seq.copy()
+        bad_reads = np.nonzero((rng.random(n_reads) < bad_rate) & (lens > 0))[0]
+        pos = off[bad_reads] + (rng.random(len(bad_reads)) * lens[bad_reads]).astype(np.uint64)
+        seq[pos.astype(np.int64)] = ord("@") if alphabet == 4 else ord("#")
+    return np.ascontiguousarray(seq), off
+
+
+def pack_reads_numpy(alphabet, seq, off, words_per_read=None):
+    """Host-side reference packer for tests: symbol i at bits [i*B, (i+1)*B) of a little-endian bit string.
+    Ambiguous / unsupported symbols pack as state 0 (the device packer does the same and flags the read)."""
+    bits = 2 if alphabet == 4 else 5
+    n = len(off) - 1
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    max_len = int(lens.max()) if n else 0
+    wpr = words_per_read or max(1, (max_len * bits + 31) // 32)
+    table = np.zeros(256, dtype=np.uint64)
+    letters = DNA_LETTERS if alphabet == 4 else AA_LETTERS
+    for i, ch in enumerate(letters):
+        table[ch] = i
+        table[ch + 32] = i
+    if alphabet == 4:
+        table[ord("U")] = table[ord("u")] = 1
+    out = np.zeros((n, wpr), dtype=np.uint32)
+    for r in range(n):
+        s = table[seq[int(off[r]):int(off[r + 1])]]
+        acc = 0
+        for i, st in enumerate(s.tolist()):
+            acc |= int(st) << (bits * i)
+        for w in range(wpr):
+            out[r, w] = (acc >> (32 * w)) & 0xFFFFFFFF
+    return out, lens.astype(np.uint32)
