@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- reads placed / second of the phylo-kmer placement hot path on MI355X.
+
+One "step" = one pass of the placement kernel over one batch of synthetic reads that is already resident in
+HBM (packed 2-bit), against the BASELINE C2 database (DNA k=10, 999 branches, ~1e7 entries, seed 42).
+Multi-GPU: reads shard across ranks, DB replicated per GPU, no collective on the data path ("weak" scaling:
+every rank places its own `--reads`).  The CPU oracle is used here ONLY as the cpu_baseline leg and as the
+pre-timing checker of a sample; the timed path is the HIP engine through the C ABI.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5mini"])
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's count)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per read (0=auto, 8/16/32/64)")
+    ap.add_argument("--table", default="auto", choices=["auto", "direct", "hash"])
+    ap.add_argument("--verify", type=int, default=2000, help="reads checked against the oracle before timing")
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--db-scale", type=float, default=1.0)
+    return ap.parse_args()
+
+
+def unpack_to_ascii(alphabet, packed_np, length):
+    """packed u32 [n, wpr] -> ASCII (for the oracle legs)."""
+    from rappas_amd import synth
+    bits = 2 if alphabet == 4 else 5
+    letters = synth.DNA_LETTERS if alphabet == 4 else synth.AA_LETTERS
+    n, wpr = packed_np.shape
+    big = np.zeros((n, wpr + 1), dtype=np.uint64)
+    big[:, :wpr] = packed_np.astype(np.uint64)
+    out = np.zeros((n, length), dtype=np.uint8)
+    for i in range(length):
+        bit = i * bits
+        w, sh = bit >> 5, bit & 31
+        v = (big[:, w] | (big[:, w + 1] << np.uint64(32))) >> np.uint64(sh)
+        out[:, i] = letters[(v & np.uint64((1 << bits) - 1)).astype(np.int64)]
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(length))
+    return out.reshape(-1), off
+
+
+def count_entries_torch(torch, sdb, packed, length, chunk=1 << 20):
+    """Exact H = sum over reads and k-mer positions of the matched row length, with plain torch ops
+    (independent of the engine): dense row-length table gather over every k-mer code."""
+    from rappas_amd import synth
+    dev = packed.device
+    k, bits, sigma = sdb.k, sdb.bits, sdb.alphabet
+    Q = length - k + 1
+    lens = (sdb.row_offsets[1:] - sdb.row_offsets[:-1]).astype(np.int64)
+    if sigma == 4:
+        dense = sdb.key_codes.astype(np.int64)
+    else:
+        dense = np.zeros(sdb.n_keys, dtype=np.int64)
+        for i in range(k):
+            dense += ((sdb.key_codes >> np.uint64(5 * i)) & np.uint64(31)).astype(np.int64) * (20 ** i)
+    table = np.zeros(sigma ** k, dtype=np.int32)
+    table[dense] = lens
+    table_t = torch.from_numpy(table).to(dev)
+    n, wpr = packed.shape
+    total = 0
+    hits = 0
+    for a in range(0, n, chunk):
+        p = packed[a:a + chunk].to(torch.int64) & 0xFFFFFFFF
+        m = p.shape[0]
+        sym = torch.empty((m, length), dtype=torch.int64, device=dev)
+        for i in range(length):
+            bit = i * bits
+            w, sh = bit >> 5, bit & 31
+            v = p[:, w] >> sh
+            if sh + bits > 32 and w + 1 < wpr:
+                v = v | (p[:, w + 1] << (32 - sh))
+            sym[:, i] = v & ((1 << bits) - 1)
+        idx = torch.zeros((m, Q), dtype=torch.int64, device=dev)
+        for i in range(k):
+            idx += sym[:, i:i + Q] * (sigma ** i)
+        ln = table_t[idx]
+        total += int(ln.sum().item())
+        hits += int((ln > 0).sum().item())
+        del p, sym, idx, ln
+    return total, hits
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the placement engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world
+
+    import rappas_amd as ra
+    from rappas_amd import synth
+
+    alphabet, k, leaves, n_keys, n_entries, rlen, n_reads_cfg = synth.CONFIGS[a.config]
+    n_reads = a.reads or n_reads_cfg
+    sdb = synth.make_config_db(a.config, seed=42, scale=a.db_scale)
+    mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "hash": ra.RK_TABLE_HASH}[a.table]
+    db = ra.PhyloKmerDB.from_synth(sdb, device=local_rank, table_mode=mode)
+    if a.lanes:
+        db.set_lanes_per_read(a.lanes)
+    pp = ra.PlacementProcess(db)
+    K = 7
+    bits = sdb.bits
+    wpr = db.packed_words(rlen)
+
+    # synthetic reads, uniform i.i.d. symbols, generated on the device straight into the packed layout
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    if alphabet == 4:
+        packed = torch.randint(-2**31, 2**31, (n_reads, wpr), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+        tail_bits = rlen * bits - 32 * (wpr - 1)
+        if tail_bits < 32:
+            packed[:, wpr - 1] &= (1 << tail_bits) - 1
+    else:
+        sym = torch.randint(0, 20, (n_reads, rlen), dtype=torch.int64, device=dev, generator=gen)
+        acc = torch.zeros((n_reads, wpr + 1), dtype=torch.int64, device=dev)
+        for i in range(rlen):
+            bit = i * bits
+            w, sh = bit >> 5, bit & 31
+            v = sym[:, i] << sh
+            acc[:, w] |= v & 0xFFFFFFFF
+            acc[:, w + 1] |= v >> 32
+        packed = acc[:, :wpr].to(torch.int32)
+        del sym, acc
+    out = dict(n_rows=torch.empty(n_reads, dtype=torch.uint8, device=dev),
+               branch=torch.empty((n_reads, K), dtype=torch.int16, device=dev),
+               score=torch.empty((n_reads, K), dtype=torch.float32, device=dev),
+               lwr=torch.empty((n_reads, K), dtype=torch.float64, device=dev),
+               flags=torch.empty(n_reads, dtype=torch.int32, device=dev))
+
+    def step():
+        pp.place_packed(packed, fixed_len=rlen, out=out, keepAtMost=K)
+
+    # ---- correctness gate on a sample before any timing (oracle = checker only) ----
+    verified = None
+    if a.verify and rank == 0:
+        from oracle import oracle as O
+        from tests.util import compare_with_oracle
+        nv = min(a.verify, n_reads)
+        step()
+        torch.cuda.synchronize()
+        seq, off = unpack_to_ascii(alphabet, packed[:nv].cpu().numpy().view(np.uint32), rlen)
+        odb = O.OracleDB.from_synth(sdb)
+        ref = odb.place(seq, off, keep_at_most=K)
+        got = ra.Placements(out["n_rows"][:nv].cpu().numpy(), out["branch"][:nv].cpu().numpy().view(np.uint16),
+                            out["score"][:nv].cpu().numpy(), out["lwr"][:nv].cpu().numpy(),
+                            out["flags"][:nv].cpu().numpy().view(np.uint32), {})
+        st = compare_with_oracle(got, ref, odb, seq, off)
+        verified = dict(reads=nv, ties=st["ties"], max_lwr_rel=st["max_lwr_rel"])
+
+    # ---- algorithmic bytes: B = ceil(R*b/8) + Q*8 + H*6 + (2 + K*14)   ----
+    Q = rlen - k + 1
+    H_total, hit_kmers = count_entries_torch(torch, sdb, packed, rlen)
+    H_mean = H_total / n_reads
+    B = math.ceil(rlen * bits / 8) + Q * 8 + H_mean * 6 + (2 + K * 14)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        evs[s][0].record()
+        step()
+        evs[s][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+
+    if rank == 0:
+        value = n_gpus * n_reads * a.steps / elapsed
+        achieved = (B * n_reads / kern_avg_s) / 1e9  # GB/s, algorithmic bytes / average kernel duration
+        peak = 8000.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                pj = json.load(open(pmc_path))
+                if pj.get("config") == a.config and pj.get("reads") == n_reads:
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "reads placed/sec (whole node), 150 bp DNA vs 10^7-kmer DB",
+            "value": value, "unit": "reads/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {'DNA' if alphabet == 4 else 'AA'} k={k}, {sdb.n_branches} branches, "
+                                   f"{sdb.n_keys} keys / {sdb.n_entries} entries phylo-kmer DB (seed 42) replicated per GPU, "
+                                   f"{n_reads} x {rlen} symbol reads per GPU per step (uniform, seed 1+rank), keep_at_most=7",
+                       "table": "direct" if db.info.table_mode == ra.RK_TABLE_DIRECT else "hash",
+                       "kernel": db.kernel_name(), "reads_per_gpu": n_reads, "sharding": f"reads x{n_gpus}, DB replicated"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "traffic": traffic, "bytes_per_read": B, "entries_per_read": H_mean,
+                         "kernel_ms": kern_avg_s * 1e3, "kernel": "place_packed_kernel"},
+            "verified_vs_oracle": verified,
+        }
+        if not a.no_cpu_baseline and n_gpus == 1:
+            from oracle import oracle as O
+            ns = min(a.cpu_sample, n_reads)
+            seq, off = unpack_to_ascii(alphabet, packed[:ns].cpu().numpy().view(np.uint32), rlen)
+            odb = O.OracleDB.from_synth(sdb)
+            odb.place(seq[:int(off[min(ns, 2000)])], off[:min(ns, 2000) + 1], keep_at_most=K)  # warm caches
+            c0 = time.perf_counter()
+            odb.place(seq, off, keep_at_most=K)
+            cdt = time.perf_counter() - c0
+            line["cpu_baseline"] = {"value": ns / cdt, "unit": "reads/s", "cores": 1, "kind": "port",
+                                    "sample": f"first {ns} reads of rank 0's batch, same DB, oracle/rappas_oracle.c "
+                                              f"(single thread, like the reference's placement loop), {cdt:.1f} s"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

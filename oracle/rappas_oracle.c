@@ -417,7 +417,8 @@ static uint32_t score_read(const ro_db *db, work_t *w, int amb_mode, const uint8
             w->seq[i] = (int8_t)c;
         }
     }
-    if (flags & RO_FLAG_BAD_CHAR) return flags; /* reference: System.exit(1) (:124-128) */
+    if (flags & RO_FLAG_BAD_CHAR) /* reference: System.exit(1) (:124-128); both conditions are reported */
+        return flags | (R < (uint64_t)k ? RO_FLAG_TOO_SHORT : 0u);
     if (R < (uint64_t)k) return flags | RO_FLAG_TOO_SHORT; /* merOrder length R-k+1 <= 0 (:145) */
     const int Q = (int)(R - (uint64_t)k + 1);   /* sk.getMerCount() (:191) */
     const int max_amb = ro_max_ambig_per_mer(k, db->alphabet);
