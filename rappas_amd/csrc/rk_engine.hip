@@ -194,7 +194,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     }
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
     std::vector<unsigned char> blob;
-    try { blob.assign(blob_bytes, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
+    try { blob.assign(blob_bytes, 0); memset(blob.data(), 0xFF, 8); /* reserved: reads as branch 0xFFFF = skip */ } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
     {
         std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
         for (uint64_t r = 0; r < n_keys; r++) {

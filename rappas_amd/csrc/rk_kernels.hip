@@ -63,20 +63,23 @@ __device__ __forceinline__ void wave_lds_fence() {
 // DNAStatesShifted.java:115-143).  AA: sum state_i << 5i (compressMer = identity, AAStates.java:195-197).
 template <int BITS>
 __device__ __forceinline__ u64 extract_code(const u32 *rec, u32 words, u32 j, u32 k) {
-    u32 bit = j * BITS;
-    u32 wi = bit >> 5, sh = bit & 31;
-    u32 w0 = rec[wi];
-    u32 w1 = (wi + 1 < words) ? rec[wi + 1] : 0u;
-    u64 lo = ((u64)w1 << 32) | w0;
+    // all loads unconditional (indices clamped, results masked) so that s_waitcnt counting stays exact
+    const u32 bit = j * BITS;
+    const u32 wi = bit >> 5, sh = bit & 31;
+    const u32 last = words - 1;
+    const u32 w0 = rec[wi];
+    const u32 i1 = wi + 1 < words ? wi + 1 : last;
+    u32 w1 = rec[i1];
+    w1 = wi + 1 < words ? w1 : 0u;
+    const u64 lo = ((u64)w1 << 32) | w0;
     u64 code = lo >> sh;
-    if (BITS * 12 + 31 > 64) {  // AA with k >= 7 needs a third word
-        u32 nbits = k * BITS;
-        if (nbits + sh > 64) {
-            u32 w2 = (wi + 2 < words) ? rec[wi + 2] : 0u;
-            code |= (u64)w2 << (64 - sh);
-        }
+    const u32 nbits = k * BITS;
+    if (BITS * 12 + 31 > 64) {  // AA with k >= 7 can need a third word
+        const u32 i2 = wi + 2 < words ? wi + 2 : last;
+        u32 w2 = rec[i2];
+        w2 = (wi + 2 < words && nbits + sh > 64) ? w2 : 0u;
+        code |= sh ? ((u64)w2 << (64 - sh)) : 0ull;
     }
-    u32 nbits = k * BITS;
     return nbits >= 64 ? code : (code & ((1ull << nbits) - 1));
 }
 
@@ -118,28 +121,30 @@ struct Cursor {
     u64 rbase;
 };
 
+// Branch-free on purpose: every lane always issues its two row loads (lanes without an entry read the reserved
+// 8 bytes at blob offset 0), so the compiler can count outstanding loads exactly (s_waitcnt vmcnt(N)) and the
+// register ring really keeps U chunks in flight.  Conditional loads made it fall back to vmcnt(0) everywhere.
 template <int G>
 __device__ __forceinline__ void cursor_issue(Cursor &c, const u64 *list, int cnt, u32 li,
                                              const unsigned char *rows, u32 &br, float &sc) {
-    if (c.rpos >= c.rlen) {
-        c.h++;
-        c.rpos = 0;
-        if (c.h < cnt) {
-            u64 d = list[c.h];
-            c.rlen = (u32)d & DESC_LEN_MASK;
-            c.rbase = (d >> DESC_LEN_BITS) << 3;
-        } else {
-            c.rlen = 0;
-        }
-    }
-    u32 e = c.rpos + li;
-    br = 0xFFFFu;
-    sc = 0.0f;
-    if (e < c.rlen) {
-        const unsigned char *p = rows + c.rbase;
-        br = ((const unsigned short *)p)[e];
-        sc = ((const float *)(p + (((c.rlen + 1) & ~1u) << 1)))[e];
-    }
+    const bool need = c.rpos >= c.rlen;
+    const int hn = c.h + (need ? 1 : 0);
+    const bool row_ok = hn < cnt;
+    const u64 d = list[row_ok ? hn : 0];
+    const u32 nlen = row_ok ? ((u32)d & DESC_LEN_MASK) : 0u;
+    c.h = hn;
+    c.rlen = need ? nlen : c.rlen;
+    c.rbase = need ? ((d >> DESC_LEN_BITS) << 3) : c.rbase;
+    c.rpos = need ? 0u : c.rpos;
+    const u32 e = c.rpos + li;
+    const bool ok = e < c.rlen;
+    const unsigned char *p = rows + (ok ? c.rbase : 0ull);
+    const u32 eb = ok ? e : 0u;
+    const u32 soff = ok ? (((c.rlen + 1) & ~1u) << 1) : 0u;
+    // no select on the loaded values (it would force the wait right here): the reserved 8 bytes at blob
+    // offset 0 are 0xFF, so lanes without an entry simply load branch id 0xFFFF = "skip".
+    br = ((const unsigned short *)p)[eb];
+    sc = ((const float *)(p + soff))[eb];
     c.rpos += G;
 }
 
@@ -321,7 +326,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         // Q = sk.getMerCount() (AmbigSequenceKnife.java:191)
         const u32 Q = (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
         const float QT = (float)(int)Q * T;  // int * float (PlacementProcess.java:728)
-        const u32 *rec = a.packed + r * a.words_per_read;
+        const u32 *rec = a.packed + (have ? r : 0ull) * a.words_per_read;  // in-bounds for idle groups too
 
         u32 pos = 0;
         while (__any(pos < Q)) {
@@ -333,9 +338,23 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                 u64 desc[PU];
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
-                    desc[u] = 0;
-                    u32 j = pos + u * G + li;
-                    if (more && j < Q) desc[u] = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                    const u32 j = pos + u * G + li;
+                    const bool okj = more && j < Q;
+                    if (DIRECT) {  // branch-free gather: out-of-range lanes re-read position 0 and drop the result later
+                        desc[u] = extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k);
+                    } else {
+                        desc[u] = 0;
+                        if (okj) desc[u] = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                    }
+                }
+                if (DIRECT) {
+#pragma unroll
+                    for (int u = 0; u < PU; u++) desc[u] = lookup_desc<BITS, DIRECT>(a.db, desc[u]);
+#pragma unroll
+                    for (int u = 0; u < PU; u++) {
+                        const u32 j = pos + u * G + li;
+                        desc[u] = (more && j < Q) ? desc[u] : 0ull;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
@@ -358,8 +377,14 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     const bool more = (pos < Q) && (cnt + G <= cap);
                     if (!__any(more)) break;
                     u64 d = 0;
-                    u32 j = pos + li;
-                    if (more && j < Q) d = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                    const u32 j = pos + li;
+                    const bool okj = more && j < Q;
+                    if (DIRECT) {
+                        u64 dd = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k));
+                        d = okj ? dd : 0ull;
+                    } else if (okj) {
+                        d = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                    }
                     bool hit = ((u32)d & DESC_LEN_MASK) != 0;
                     u64 b = __ballot(hit);
                     u32 sub = (u32)((b >> (gi * G)) & gmask);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 passes for the placement kernel (run on the GPU box through gpurun).
+# usage: scripts/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r01}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --verify 0 --no-cpu-baseline $*"
+run() { # name, rocprof args...
+  local name=$1; shift
+  timeout -k 10 280 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+}
+run trace --kernel-trace --stats &&
+run pmc1 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU &&
+run pmc2 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_WAVES &&
+run pmc3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE &&
+run pmc4 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+find "$OUT" -name "*.csv" | head -30
