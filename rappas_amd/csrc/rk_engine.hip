@@ -342,7 +342,7 @@ extern "C" int rk_set_lanes_per_read(rk_db *db, uint32_t lanes) {
 // launch geometry
 // ------------------------------------------------------------------------------------------------
 struct Geometry {
-    uint32_t G, NG, s_stride, list_cap, kcap, pu;
+    uint32_t G, NG, s_stride, list_cap, pu;
     size_t lds_per_wave;
     uint32_t waves_per_cu;
 };
@@ -351,7 +351,7 @@ static uint32_t probe_unroll(uint32_t G) { return G <= 16 ? 4 : (G == 32 ? 2 : 1
 
 static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) {
     const uint32_t nb = db->info.n_branches;
-    const uint32_t s_stride = (nb + 1) & ~1u;
+    const uint32_t s_stride = (nb + 2) & ~1u;  // >= nb + 1: word nb is the scratch slot of apply_entry
     const size_t target = db->lds_per_cu / 8;  // aim for >= 8 waves per CU
     auto bytes_for = [&](uint32_t G, uint32_t cap) { return (size_t)(64 / G) * ((size_t)s_stride * 4 + (size_t)cap * 8); };
     uint32_t G = db->lanes_per_read;
@@ -359,12 +359,12 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         G = 64;
         for (uint32_t cand : {16u, 32u, 64u}) {
             if (cand < keep_at_most) continue;
-            if (bytes_for(cand, probe_unroll(cand) * cand) <= target) { G = cand; break; }
+            if (bytes_for(cand, probe_unroll(cand) * cand + 40) <= target) { G = cand; break; }
         }
     }
     if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
     const uint32_t NG = 64 / G, pu = probe_unroll(G);
-    const uint32_t min_cap = pu * G < 64 ? 64 : pu * G;
+    const uint32_t min_cap = pu * G + 40;  // probe batch + zero sentinel + 16 winner slots + margin (select_topk)
     // list capacity: whatever is left of the per-wave LDS target, clamped to [min_cap, 256]
     size_t per_group_target = target / NG;
     uint32_t cap = min_cap;
@@ -374,7 +374,6 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         if (cap < min_cap) cap = min_cap;
     }
     g.G = G; g.NG = NG; g.s_stride = s_stride; g.list_cap = cap; g.pu = pu;
-    g.kcap = keep_at_most <= 8 ? 8 : 16;
     g.lds_per_wave = bytes_for(G, cap);
     if (g.lds_per_wave > db->lds_per_cu)
         return fail(RK_ERR_UNSUPPORTED, "n_branches=%u needs %zu B of LDS per read, more than one CU has (%zu B)", nb, g.lds_per_wave, db->lds_per_cu);
@@ -383,14 +382,13 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
     return RK_OK;
 }
 
-template <int G, int BITS, bool DIRECT, int KCAP>
-static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream, bool dry) {
+template <int G, int BITS, bool DIRECT, bool WIDE>
+static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
     constexpr int PU = G <= 16 ? 4 : (G == 32 ? 2 : 1);
     constexpr int U = 8;
-    auto kern = place_packed_kernel<G, BITS, DIRECT, KCAP, U, PU>;
+    auto kern = place_packed_kernel<G, BITS, DIRECT, WIDE, U, PU>;
     const uint32_t wpb = db->waves_per_block;
     const size_t lds = g.lds_per_wave * wpb;
-    if (dry) return RK_OK;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t n_tiles = (args.n_reads + g.NG - 1) / g.NG;
     uint64_t blocks = (uint64_t)db->cu_count * ((g.waves_per_cu + wpb - 1) / wpb);
@@ -403,31 +401,31 @@ static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &a
 }
 
 template <int G, int BITS, bool DIRECT>
-static int launch_k(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry) {
-    if (g.kcap == 8) return launch_variant<G, BITS, DIRECT, 8>(db, g, a, s, dry);
-    if constexpr (G >= 16) return launch_variant<G, BITS, DIRECT, 16>(db, g, a, s, dry);
-    else return fail(RK_ERR_INVALID, "keep_at_most > 8 needs lanes_per_read >= 16");
+static int launch_w(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
+    // 32-bit row offsets whenever the row blob is < 4 GiB
+    return db->info.rows_bytes < (1ull << 32) ? launch_variant<G, BITS, DIRECT, false>(db, g, a, s)
+                                              : launch_variant<G, BITS, DIRECT, true>(db, g, a, s);
 }
 template <int G, int BITS>
-static int launch_t(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry) {
-    return db->info.table_mode == RK_TABLE_DIRECT ? launch_k<G, BITS, true>(db, g, a, s, dry) : launch_k<G, BITS, false>(db, g, a, s, dry);
+static int launch_t(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
+    return db->info.table_mode == RK_TABLE_DIRECT ? launch_w<G, BITS, true>(db, g, a, s) : launch_w<G, BITS, false>(db, g, a, s);
 }
 template <int G>
-static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry) {
-    return db->info.bits_per_symbol == 2 ? launch_t<G, 2>(db, g, a, s, dry) : launch_t<G, 5>(db, g, a, s, dry);
+static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
+    return db->info.bits_per_symbol == 2 ? launch_t<G, 2>(db, g, a, s) : launch_t<G, 5>(db, g, a, s);
 }
-static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s, bool dry = false) {
+static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
     switch (g.G) {
-    case 8: return launch_b<8>(db, g, a, s, dry);
-    case 16: return launch_b<16>(db, g, a, s, dry);
-    case 32: return launch_b<32>(db, g, a, s, dry);
-    default: return launch_b<64>(db, g, a, s, dry);
+    case 8: return launch_b<8>(db, g, a, s);
+    case 16: return launch_b<16>(db, g, a, s);
+    case 32: return launch_b<32>(db, g, a, s);
+    default: return launch_b<64>(db, g, a, s);
     }
 }
 
 template <int BITS, bool DIRECT>
 static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, const AmbArgs &m, hipStream_t stream) {
-    const size_t lds = (size_t)args.s_stride * 12;
+    const size_t lds = (size_t)args.s_stride * 12 + (size_t)ASCII_LIST_CAP * 8;
     if (lds > db->lds_per_cu)
         return fail(RK_ERR_UNSUPPORTED, "ambiguity path keeps 3 per-branch vectors in LDS: n_branches=%u needs %zu B > %zu B", db->info.n_branches, lds, db->lds_per_cu);
     const uint64_t groups = (args.n_reads + 63) / 64;
@@ -436,15 +434,9 @@ static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, const AmbArgs 
     uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
     if (blocks > groups) blocks = groups;
     if (!blocks) return RK_OK;
-    if (args.keep_at_most <= 8) {
-        auto kern = place_ascii_kernel<BITS, DIRECT, 8>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
-    } else {
-        auto kern = place_ascii_kernel<BITS, DIRECT, 16>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
-    }
+    auto kern = place_ascii_kernel<BITS, DIRECT>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
     HIP_TRY(hipGetLastError());
     return RK_OK;
 }
@@ -469,9 +461,9 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     rk_db *m = const_cast<rk_db *>(db);
     if (choose_geometry(db, 7, g) != RK_OK) return "";
     char buf[160];
-    snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,KCAP=%u,U=8,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
-             g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : "HASH", g.kcap, g.pu,
-             g.lds_per_wave, g.list_cap, g.waves_per_cu);
+    snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=8,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
+             g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : "HASH",
+             db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();
 }

@@ -115,118 +115,173 @@ __device__ __forceinline__ u64 lookup_desc(const DbView &db, u64 code) {
 // ------------------------------------------------------------------------------------------------
 // accumulate: row cursor + register ring
 // ------------------------------------------------------------------------------------------------
+// Offsets into the row blob are 32-bit when the blob is < 4 GiB (WIDE=false: the loads use the
+// scalar-base + 32-bit-vgpr-offset form, no 64-bit VALU address arithmetic), 64-bit otherwise.
+template <bool WIDE> struct OffsetT { typedef u32 type; };
+template <> struct OffsetT<true> { typedef u64 type; };
+
+template <bool WIDE>
 struct Cursor {
-    int h;
-    u32 rlen, rpos;
-    u64 rbase;
+    typedef typename OffsetT<WIDE>::type off_t;
+    int h;      // index of the current row in the hit list
+    int rem;    // entries of the current row not yet issued (<= 0: fetch the next row)
+    off_t boff; // byte offset of the next branch-id chunk
+    off_t soff; // byte offset of the next score chunk
+    u64 dn;     // list[min(h + 1, cnt)], fetched one step ahead so its LDS latency is off the critical path
 };
 
 // Branch-free on purpose: every lane always issues its two row loads (lanes without an entry read the reserved
-// 8 bytes at blob offset 0), so the compiler can count outstanding loads exactly (s_waitcnt vmcnt(N)) and the
-// register ring really keeps U chunks in flight.  Conditional loads made it fall back to vmcnt(0) everywhere.
-template <int G>
-__device__ __forceinline__ void cursor_issue(Cursor &c, const u64 *list, int cnt, u32 li,
+// 8 bytes at blob offset 0, which hold branch id 0xFFFF = "skip"), and nothing selects on a loaded value here,
+// so the compiler counts outstanding loads exactly (s_waitcnt vmcnt(N)) and the register ring keeps U chunks
+// in flight per lane.  list[cnt] must be a zero descriptor (sentinel).
+template <int G, bool WIDE>
+__device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, int cnt, u32 li2, u32 li4, int li,
                                              const unsigned char *rows, u32 &br, float &sc) {
-    const bool need = c.rpos >= c.rlen;
-    const int hn = c.h + (need ? 1 : 0);
-    const bool row_ok = hn < cnt;
-    const u64 d = list[row_ok ? hn : 0];
-    const u32 nlen = row_ok ? ((u32)d & DESC_LEN_MASK) : 0u;
+    typedef typename OffsetT<WIDE>::type off_t;
+    const bool need = c.rem <= 0;
+    int hn = c.h + (need ? 1 : 0);
+    hn = hn < cnt ? hn : cnt;
+    const u64 d = c.dn;
+    const int hp = hn + 1 < cnt ? hn + 1 : cnt;
+    c.dn = list[hp];
+    const u32 len = (u32)d & DESC_LEN_MASK;
+    const off_t off = (off_t)(d >> DESC_LEN_BITS) << 3;
     c.h = hn;
-    c.rlen = need ? nlen : c.rlen;
-    c.rbase = need ? ((d >> DESC_LEN_BITS) << 3) : c.rbase;
-    c.rpos = need ? 0u : c.rpos;
-    const u32 e = c.rpos + li;
-    const bool ok = e < c.rlen;
-    const unsigned char *p = rows + (ok ? c.rbase : 0ull);
-    const u32 eb = ok ? e : 0u;
-    const u32 soff = ok ? (((c.rlen + 1) & ~1u) << 1) : 0u;
-    // no select on the loaded values (it would force the wait right here): the reserved 8 bytes at blob
-    // offset 0 are 0xFF, so lanes without an entry simply load branch id 0xFFFF = "skip".
-    br = ((const unsigned short *)p)[eb];
-    sc = ((const float *)(p + soff))[eb];
-    c.rpos += G;
+    c.rem = need ? (int)len : c.rem;
+    c.boff = need ? off : c.boff;
+    c.soff = need ? (off_t)(off + (((len + 1) & ~1u) << 1)) : c.soff;
+    const bool ok = li < c.rem;
+    const off_t bo = ok ? (off_t)(c.boff + li2) : (off_t)0;
+    const off_t so = ok ? (off_t)(c.soff + li4) : (off_t)0;
+    br = *(const unsigned short *)(rows + bo);
+    sc = *(const float *)(rows + so);
+    c.rem -= G;
+    c.boff += 2 * G;
+    c.soff += 4 * G;
 }
 
 // S[x] update of PlacementProcess.java:726-733: first touch seeds fl(Q*T), then S = fl(S + fl(v - T)).
-__device__ __forceinline__ void apply_entry(u32 *S, u32 br, float sc, float QT, float T) {
-    if (br != 0xFFFFu) {
-        u32 old = S[br];
-        float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
-        float d = sc - T;
-        float nw = base + d;
-        S[br] = __float_as_uint(nw);
-    }
+// Branch-free: lanes without an entry (br == 0xFFFF) update the group's scratch word S[nb] instead, so the
+// compiler can overlap the LDS read latency with the address arithmetic of the next ring slot.
+__device__ __forceinline__ void apply_entry(u32 *S, u32 nb, u32 br, float sc, float QT, float T) {
+    const u32 idx = (br != 0xFFFFu) ? br : nb;
+    const u32 old = S[idx];
+    const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+    const float d = sc - T;
+    const float nw = base + d;
+    S[idx] = __float_as_uint(nw);
+}
+__device__ __forceinline__ void apply_entry_masked(u32 *S, u32 br, float sc, float QT, float T) {
+    u32 old = S[br];
+    float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+    float d = sc - T;
+    float nw = base + d;
+    S[br] = __float_as_uint(nw);
 }
 
-template <int G, int U>
-__device__ __forceinline__ void accumulate_list(u32 *S, const u64 *list, int cnt, u32 li,
+template <int G, int U, bool WIDE>
+__device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list, int cnt, u32 li,
                                                 const unsigned char *rows, float QT, float T) {
-    Cursor c;
-    c.h = -1; c.rlen = 0; c.rpos = 0; c.rbase = 0;
+    Cursor<WIDE> c;
+    c.h = -1; c.rem = 0; c.boff = 0; c.soff = 0;
+    c.dn = list[0];
+    const u32 li2 = li * 2, li4 = li * 4;
     u32 br[U];
     float sc[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) cursor_issue<G>(c, list, cnt, li, rows, br[u], sc[u]);
+    for (int u = 0; u < U; u++) cursor_issue<G, WIDE>(c, list, cnt, li2, li4, (int)li, rows, br[u], sc[u]);
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_entry(S, br[u], sc[u], QT, T);
-            cursor_issue<G>(c, list, cnt, li, rows, br[u], sc[u]);
+            apply_entry(S, nb, br[u], sc[u], QT, T);
+            cursor_issue<G, WIDE>(c, list, cnt, li2, li4, (int)li, rows, br[u], sc[u]);
         }
         if (!__any(c.h < cnt)) break;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) apply_entry(S, br[u], sc[u], QT, T);
+    for (int u = 0; u < U; u++) apply_entry(S, nb, br[u], sc[u], QT, T);
 }
 
 // ------------------------------------------------------------------------------------------------
 // select: top-K + LWR + output (A8/A9: PlacementProcess.java:396-451, :974-1025)
+// Order among candidates is the total order of the packed key: score desc (Float.compare), then branch id asc.
 // ------------------------------------------------------------------------------------------------
-template <int KCAP>
-__device__ __forceinline__ void topk_insert(u64 (&t)[KCAP], u64 key) {
-#pragma unroll
-    for (int i = 0; i < KCAP; i++) {
-        bool bigger = key > t[i];
-        u64 tmp = bigger ? t[i] : key;
-        t[i] = bigger ? key : t[i];
-        key = tmp;
+// Exact top-K of list[0..c): every lane ranks the candidates it owns against all others (LDS broadcast reads);
+// rank r < K goes to win[r].  Returns min(c, K).  Keys are unique (they embed the branch id).
+template <int G>
+__device__ __forceinline__ int rank_candidates(const u64 *list, int c, u64 *win, int K, u32 li) {
+    for (int j = (int)li; j < c; j += G) {
+        const u64 mine = list[j];
+        int rank = 0;
+        for (int t = 0; t < c; t++) rank += (list[t] > mine) ? 1 : 0;
+        if (rank < K) win[rank] = mine;
     }
+    wave_lds_fence();
+    return c < K ? c : K;
 }
 
-// Scans S[0..nb) with the G lanes of the group, resets it to UNTOUCHED, leaves rank-r winner in lane r (r < K).
-// Returns numBest (uniform in the group); win_key valid in lanes li < numBest.
-template <int G, int KCAP>
-__device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, int K, u64 &win_key) {
-    u64 t[KCAP];
-#pragma unroll
-    for (int i = 0; i < KCAP; i++) t[i] = 0;
+// Scans S[0..nb) with the G lanes of a group and resets it to UNTOUCHED; leaves the rank-r winner key in lane r.
+//   pass 1  per-lane maximum (float compare; the UNTOUCHED pattern is a NaN and never wins);
+//   tau     the K-th largest of the G lane maxima: at least K scores are >= tau, so it bounds the answer from below;
+//   pass 2  entries with key >= tau are compacted into the (now idle) hit list; if the list fills up it is pruned
+//           to its exact top-K and tau is raised -- correct for any score distribution;
+//   rank    exact top-K of the few survivors.
+// `list` has `cap` u64 slots; the last 16 are the winners' scratch.  Returns numBest (group-uniform).
+template <int G>
+__device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    u64 *win = list + (cap - 16);
+    const int capc = cap - 16;
+    // ---- pass 1 ----
+    float mo = -INFINITY;
+    u32 mi = 0xFFFFu;
     for (u32 i = li; i < nb; i += G) {
-        u32 raw = S[i];
-        if (raw != S_UNTOUCHED) {
-            S[i] = S_UNTOUCHED;
-            u64 key = make_key(raw, i);
-            if (key > t[KCAP - 1]) topk_insert<KCAP>(t, key);
+        const float v = __uint_as_float(S[i]);
+        const bool gt = v > mo;  // false for the NaN marker; ties keep the smaller branch id
+        mo = gt ? v : mo;
+        mi = gt ? i : mi;
+    }
+    const u64 km = (mi != 0xFFFFu) ? make_key(__float_as_uint(mo), mi) : 0ull;
+    // ---- tau = K-th largest lane maximum (0 if fewer than K lanes saw anything) ----
+    int rank = 0;
+#pragma unroll
+    for (int s = 1; s < G; s++) rank += (shfl_xor64(km, s, G) > km) ? 1 : 0;
+    u64 tau = (rank == K - 1) ? km : 0ull;
+#pragma unroll
+    for (int s = 1; s < G; s <<= 1) {
+        u64 o = shfl_xor64(tau, s, G);
+        tau = o > tau ? o : tau;
+    }
+    // ---- pass 2 ----
+    int c = 0;
+    for (u32 i0 = 0; i0 < nb; i0 += G) {
+        const u32 i = i0 + li;
+        u32 raw = S_UNTOUCHED;
+        if (i < nb) { raw = S[i]; S[i] = S_UNTOUCHED; }
+        const u64 key = (raw != S_UNTOUCHED) ? make_key(raw, i) : 0ull;
+        const bool cand = key != 0 && key >= tau;
+        const u64 b = __ballot(cand);
+        const u64 sub = (b >> (gi * G)) & gmask;
+        if (sub) {  // group-uniform
+            if (c + G > capc) {  // prune: keep the exact top-K, raise tau
+                wave_lds_fence();
+                const int kept = rank_candidates<G>(list, c, win, K, li);
+                if ((int)li < kept) list[li] = win[li];
+                if (kept == K) tau = win[K - 1];
+                wave_lds_fence();
+                c = kept;
+            }
+            const bool still = cand && key >= tau;
+            const u64 b2 = __ballot(still);
+            const u64 sub2 = (b2 >> (gi * G)) & gmask;
+            if (still) list[c + __builtin_popcountll(sub2 & ((1ull << li) - 1))] = key;
+            c += __builtin_popcountll(sub2);
         }
     }
-    win_key = 0;
-    int num = 0;
-    for (int r = 0; r < K; r++) {
-        u64 m = t[0];
-#pragma unroll
-        for (int s = 1; s < G; s <<= 1) {
-            u64 o = shfl_xor64(m, s, G);
-            m = o > m ? o : m;
-        }
-        if (m == 0) break;  // group-uniform
-        num++;
-        if (t[0] == m) {  // unique winner (branch ids are unique) pops its head
-#pragma unroll
-            for (int i = 0; i < KCAP - 1; i++) t[i] = t[i + 1];
-            t[KCAP - 1] = 0;
-        }
-        if ((int)li == r) win_key = m;
-    }
+    wave_lds_fence();
+    const int num = rank_candidates<G>(list, c, win, K, li);
+    win_key = ((int)li < num) ? win[li] : 0ull;
+    wave_lds_fence();
     return num;
 }
 
@@ -287,7 +342,7 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
 // ------------------------------------------------------------------------------------------------
 // main placement kernel: reads packed 2-bit / 5-bit, no ambiguity characters
 // ------------------------------------------------------------------------------------------------
-template <int G, int BITS, bool DIRECT, int KCAP, int U, int PU>
+template <int G, int BITS, bool DIRECT, bool WIDE, int U, int PU>
 __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     constexpr int NG = 64 / G;
     extern __shared__ u32 lds[];
@@ -303,7 +358,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     const u32 k = a.db.k;
     const float T = a.db.T;
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
-    const int cap = (int)a.list_cap;
+    const int cap = (int)a.list_cap - 1;  // one slot is kept for the zero sentinel behind the hits
 
     for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
     wave_lds_fence();
@@ -393,15 +448,16 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     if (more) pos += G;
                 }
             }
+            if (li == 0) list[cnt] = 0;  // sentinel: an empty row ends the cursor
             wave_lds_fence();
             // ---- accumulate in k-mer order ----
-            if (__any(cnt > 0)) accumulate_list<G, U>(S, list, cnt, li, a.db.rows, QT, T);
+            if (__any(cnt > 0)) accumulate_list<G, U, WIDE>(S, nb, list, cnt, li, a.db.rows, QT, T);
             wave_lds_fence();
         }
 
         // ---- select + weigh + store (also resets S) ----
         u64 win_key;
-        int numBest = select_topk<G, KCAP>(S, nb, li, (int)a.keep_at_most, win_key);
+        int numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
         wave_lds_fence();
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
@@ -412,6 +468,8 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
 // ASCII kernel for reads that contain ambiguity characters (one wave per read, sequential k-mers).
 // A1/A2/A7: AmbigSequenceKnife.java:98-272, PlacementProcess.java:1129-1236.
 // ------------------------------------------------------------------------------------------------
+constexpr int ASCII_LIST_CAP = 160;
+
 struct AmbArgs {
     const unsigned char *ascii;
     const u64 *seq_off;
@@ -428,10 +486,10 @@ __device__ __forceinline__ void amb_apply_plain(const DbView &db, u32 *S, u64 de
     const unsigned char *p = db.rows + ((desc >> DESC_LEN_BITS) << 3);
     const unsigned short *bp = (const unsigned short *)p;
     const float *sp = (const float *)(p + (((len + 1) & ~1u) << 1));
-    for (u32 e = lane; e < len; e += 64) apply_entry(S, bp[e], sp[e], QT, T);
+    for (u32 e = lane; e < len; e += 64) apply_entry_masked(S, bp[e], sp[e], QT, T);
 }
 
-template <int BITS, bool DIRECT, int KCAP>
+template <int BITS, bool DIRECT>
 __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m) {
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
@@ -439,6 +497,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     u32 *S = lds;
     float *Samb = (float *)(lds + a.s_stride);
     u32 *Camb = lds + 2 * a.s_stride;
+    u64 *clist = (u64 *)(lds + 3 * a.s_stride);  // ASCII_LIST_CAP candidate slots for select_topk
     const u32 k = a.db.k;
     const float T = a.db.T, P = a.db.P;
     for (u32 i = lane; i < a.s_stride; i += 64) { S[i] = S_UNTOUCHED; Samb[i] = 0.0f; Camb[i] = 0; }
@@ -548,7 +607,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
             }
             wave_lds_fence();
             u64 win_key;
-            int numBest = select_topk<64, KCAP>(S, nb, lane, (int)a.keep_at_most, win_key);
+            int numBest = select_topk<64>(S, nb, lane, 0u, (int)a.keep_at_most, clist, ASCII_LIST_CAP, win_key);
             wave_lds_fence();
             weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
             (void)kmask;
