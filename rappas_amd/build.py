@@ -1,4 +1,4 @@
-"""Build the native pieces in-tree: the HIP engine (gfx950) and, separately, the CPU oracle used by tests.
+"""Build the native engine in-tree (gfx950 HIP kernels + C ABI).
 
 `python -m rappas_amd.build` or `rappas_amd.build.build_engine()`.  hipcc cross-compiles without a GPU.
 """
@@ -10,8 +10,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rappas_amd", "csrc")
 ENGINE_SO = os.path.join(ROOT, "rappas_amd", "librappas_place.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -51,17 +49,6 @@ def build_engine(force=False, verbose=False):
     return ENGINE_SO
 
 
-def build_oracle(force=False, verbose=False):
-    """Test infrastructure only (see oracle/rappas_oracle.h)."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("rappas_oracle.c", "rappas_oracle.h", "Makefile")]
-    if not force and not _stale(ORACLE_SO, srcs):
-        return ORACLE_SO
-    cmd = ["make", "-C", ORACLE_DIR] + (["-B"] if force else [])
-    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
-    return ORACLE_SO
-
-
 if __name__ == "__main__":
     build_engine(force="--force" in sys.argv, verbose=True)
-    build_oracle(force="--force" in sys.argv, verbose=True)
-    print("built:", ENGINE_SO, ORACLE_SO)
+    print("built:", ENGINE_SO)

@@ -1,0 +1,267 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Bar: flags / n_rows / branches identical, scores bit-equal (float32), LWR within 1e-9 relative (north_star: 1e-5).
+Reads whose top-(K+1) hold an exact float tie are compared as described in tests/util.py (the reference's order
+among equal scores depends on its hash-map layout)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rappas_amd as ra
+from rappas_amd import _lib, synth
+from oracle import oracle as O
+from tests import golden_util as GU
+from tests.util import compare_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"direct": ra.RK_TABLE_DIRECT, "hash": ra.RK_TABLE_HASH}
+
+
+@pytest.fixture(scope="module")
+def c2_small():
+    sdb = synth.make_config_db("C2", scale=0.2)
+    return sdb, O.OracleDB.from_synth(sdb)
+
+
+def run_case(sdb, odb, seq, off, table="direct", lanes=0, amb="mean", **kw):
+    db = ra.PhyloKmerDB.from_synth(sdb, table_mode=MODES[table])
+    try:
+        db.set_lanes_per_read(lanes)
+        pp = ra.PlacementProcess(db, ns_bound=kw.pop("ns_bound", float("-inf")))
+        K = kw.get("keepAtMost", 7)
+        got = pp.processQueries(seq, off, treatAmbiguities=amb != "skip", treatAmbiguitiesWithMax=amb == "max", **kw)
+        ref = odb.place(seq, off, keep_at_most=K, keep_factor=kw.get("keepFactor", 0.01), amb_mode=GU.AMB[amb],
+                        ns_bound=pp.ns_bound)
+        st = compare_with_oracle(got, ref, odb, seq, off, amb_mode=GU.AMB[amb])
+        assert got.counters["reads"] == len(off) - 1
+        assert got.counters["placed"] == int((ref["flags"] & 1).sum())
+        return got, ref, st
+    finally:
+        db.close()
+
+
+@pytest.mark.parametrize("table", ["direct", "hash"])
+@pytest.mark.parametrize("lanes", [0, 8, 16, 32, 64])
+def test_c1_full(table, lanes):
+    """BASELINE config 1: DNA k=8, 99 branches, 1k x 150 bp reads."""
+    sdb = synth.make_config_db("C1")
+    seq, off = synth.make_reads(4, 1000, 150, seed=1)
+    _, _, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, table, lanes)
+    assert st["placed"] == 1000
+
+
+@pytest.mark.parametrize("table", ["direct", "hash"])
+@pytest.mark.parametrize("lanes", [0, 16, 32, 64])
+def test_c2_scaled(c2_small, table, lanes):
+    """BASELINE config 2 (DNA k=10, 999 branches) at 20 % DB size so the oracle finishes in seconds."""
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 4000, 150, seed=1)
+    run_case(sdb, odb, seq, off, table, lanes)
+
+
+@pytest.mark.parametrize("table", ["direct", "hash"])
+@pytest.mark.parametrize("lanes", [0, 8, 64])
+def test_c4_protein(table, lanes):
+    """BASELINE config 4: AA k=5 (5-bit packing), 399 branches, 100 aa reads."""
+    sdb = synth.make_config_db("C4", scale=0.3)
+    seq, off = synth.make_reads(20, 3000, 100, seed=1)
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, table, lanes)
+
+
+@pytest.mark.parametrize("table", ["direct", "hash"])
+def test_c5_large_tree_scaled(table):
+    """BASELINE config 5's tree and k (19 999 branches, k=12, 250 bp) with a DB one test can hold; rows ~50 entries."""
+    sdb = synth.make_db(4, 12, 19999, 60_000, 3_000_000, seed=42)
+    seq, off = synth.make_reads(4, 400, 250, seed=1)
+    # make the reads hit: overwrite windows with DB k-mers
+    rng = np.random.default_rng(3)
+    letters = synth.DNA_LETTERS
+    for r in range(400):
+        for _ in range(12):
+            code = int(sdb.key_codes[rng.integers(0, sdb.n_keys)])
+            p = int(off[r]) + int(rng.integers(0, 238))
+            seq[p:p + 12] = letters[[(code >> (2 * i)) & 3 for i in range(12)]]
+    _, ref, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, table)
+    assert st["placed"] > 300
+
+
+@pytest.mark.parametrize("amb", ["mean", "max", "skip"])
+@pytest.mark.parametrize("alphabet,cfg", [(4, "C1"), (20, "C4")])
+def test_ambiguity_bad_and_ragged_reads(alphabet, cfg, amb):
+    """IUPAC / X ambiguity (mean, max, --noamb), unsupported characters, lengths from 0 to full."""
+    sdb = synth.make_config_db(cfg, scale=0.3 if cfg == "C4" else 1.0)
+    rl = synth.CONFIGS[cfg][5]
+    seq, off = synth.make_reads(alphabet, 1500, rl, seed=11, amb_rate=0.01, bad_rate=0.02, var_len=rl)
+    got, ref, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, amb=amb)
+    assert (got.flags & ra.RK_FLAG_AMBIGUOUS).any() and (got.flags & ra.RK_FLAG_BAD_CHAR).any()
+    assert (got.flags & ra.RK_FLAG_TOO_SHORT).any()
+
+
+def test_all_reads_ambiguous_dense():
+    sdb = synth.make_config_db("C1")
+    seq, off = synth.make_reads(4, 300, 150, seed=4, amb_rate=0.08)
+    for amb in ("mean", "max"):
+        run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, amb=amb)
+
+
+@pytest.mark.parametrize("path", GU.cases(), ids=lambda p: p.split("/")[-1][:-5])
+def test_golden_vectors(path):
+    """Hand-derived vectors (tests/golden/): same inputs through the C ABI."""
+    g = GU.load(path)
+    codes, off, br, sc = g["csr"]
+    for table in ("direct", "hash"):
+        db = ra.PhyloKmerDB(g["alphabet"], g["k"], g["n_branches"], g["T"], g["P"], codes, off, br, sc,
+                            table_mode=MODES[table])
+        odb = O.OracleDB(g["alphabet"], g["k"], g["n_branches"], g["T"], g["P"], codes, off, br, sc)
+        for run in g["runs"]:
+            p = run["params"]
+            K = p["keep_at_most"]
+            seq, roff = GU.reads_of(run)
+            pp = ra.PlacementProcess(db, ns_bound=p.get("ns_bound", float("-inf")))
+            got = pp.processQueries(seq, roff, keepAtMost=K, keepFactor=p["keep_factor"],
+                                    treatAmbiguities=p["amb_mode"] != "skip", treatAmbiguitiesWithMax=p["amb_mode"] == "max")
+            n_rows, branch, score, lwr, flags = GU.expected_arrays(run, K)
+            assert (got.flags == flags).all(), (p, got.flags, flags)
+            assert (got.n_rows == n_rows).all(), p
+            assert (got.score.view(np.uint32) == score.view(np.uint32)).all(), p
+            np.testing.assert_allclose(got.lwr, lwr, rtol=1e-9, atol=0)
+            for i, e in enumerate(run["expected"]):
+                if (got.branch[i] != branch[i]).any():
+                    assert GU.has_tie(e), (p, e["read"], got.branch[i], branch[i])   # tie policy: score desc, branch asc
+                    for j in range(int(got.n_rows[i])):
+                        assert e["S"][str(int(got.branch[i, j]))] == int(got.score[i, j].view(np.uint32))
+        db.close()
+
+
+def test_tie_rule_is_branch_ascending():
+    g = GU.load([p for p in GU.cases() if "topk_dna_k5" in p][0])
+    codes, off, br, sc = g["csr"]
+    db = ra.PhyloKmerDB(4, g["k"], g["n_branches"], g["T"], g["P"], codes, off, br, sc)
+    got = ra.PlacementProcess(db).processQueries(np.frombuffer(b"CCCCC", np.uint8), np.array([0, 5], np.uint64), keepFactor=0.0)
+    assert got.n_rows[0] == 3 and got.branch[0, :3].tolist() == [2, 4, 9]     # three equal scores
+    assert len(set(got.score[0, :3].tolist())) == 1
+    db.close()
+
+
+@pytest.mark.parametrize("K,kf", [(1, 0.01), (2, 0.5), (7, 0.0), (7, 1.0), (8, 0.01), (16, 0.001)])
+def test_keep_at_most_and_keep_factor(c2_small, K, kf):
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 1500, 150, seed=2)
+    got, _, _ = run_case(sdb, odb, seq, off, keepAtMost=K, keepFactor=kf)
+    if kf == 0.0:
+        assert (got.n_rows[got.flags & 1 == 1] == K).all()
+
+
+def test_ns_bound_gate(c2_small):
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 800, 150, seed=5)
+    got, ref, _ = run_case(sdb, odb, seq, off, ns_bound=-575.0)
+    gated = (got.flags & ra.RK_FLAG_BELOW_NSBOUND) != 0
+    assert gated.any() and not gated.all()
+    assert (got.n_rows[gated] == 0).all()
+
+
+def test_edge_lengths_and_empty_batch():
+    sdb = synth.make_config_db("C1")
+    odb = O.OracleDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    pp = ra.PlacementProcess(db)
+    got = pp.processQueries(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert got.n_rows.shape == (0,) and got.counters["reads"] == 0
+    reads = [b"", b"A", b"ACGTACG", b"ACGTACGT", b"ACGTACGTA", b"N" * 20, b"ACGT" * 3 + b"!" + b"ACGT" * 3,
+             b"acgu" * 10, bytes(synth.make_reads(4, 1, 3000, seed=8)[0]), bytes(synth.make_reads(4, 1, 16, seed=9)[0])]
+    seq = np.frombuffer(b"".join(reads), np.uint8)
+    off = np.zeros(len(reads) + 1, np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    got = pp.processQueries(seq, off)
+    ref = odb.place(seq, off)
+    compare_with_oracle(got, ref, odb, seq, off)
+    assert got.flags[0] & ra.RK_FLAG_TOO_SHORT and got.flags[2] & ra.RK_FLAG_TOO_SHORT   # R=0, R=k-1
+    assert not got.flags[3] & ra.RK_FLAG_TOO_SHORT                                      # R=k
+    assert got.flags[6] & ra.RK_FLAG_BAD_CHAR and got.n_rows[6] == 0
+    assert got.flags[8] & ra.RK_FLAG_PLACED                                             # 3000 bp: several list flushes
+    db.close()
+
+
+def test_long_reads_and_long_rows():
+    """Rows longer than the lane group (chunked) and reads whose hits overflow the LDS hit list (flushed in order)."""
+    sdb = synth.make_db(4, 8, 999, 30_000, 6_000_000, seed=3)          # mean row 200 entries
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_reads(4, 300, 1200, seed=6, var_len=900)
+    for lanes in (0, 8, 16, 32, 64):
+        run_case(sdb, odb, seq, off, "direct", lanes)
+    run_case(sdb, odb, seq, off, "hash", 0)
+
+
+def test_select_prune_path():
+    """Few lanes own all touched branches -> the candidate list overflows and is pruned in place (select_topk)."""
+    rng = np.random.default_rng(12)
+    nb, k = 999, 6
+    keys = rng.choice(4 ** k, 3000, replace=False).astype(np.uint64)
+    allowed = np.array([b for b in range(1, nb) if b % 16 < 5], np.uint16)
+    rows_b, rows_s, off = [], [], [0]
+    P, T = synth.thresholds(1.5, 4, k)
+    for _ in keys:
+        sel = rng.choice(allowed, size=int(rng.integers(50, 250)), replace=False)
+        rows_b.append(np.sort(sel))
+        rows_s.append((T * rng.random(len(sel), dtype=np.float32)).astype(np.float32))
+        off.append(off[-1] + len(sel))
+    sdb = synth.SynthDB(4, k, nb, P, T, keys, np.array(off, np.uint64), np.concatenate(rows_b).astype(np.uint16),
+                        np.concatenate(rows_s))
+    odb = O.OracleDB.from_synth(sdb)
+    seq, roff = synth.make_reads(4, 200, 150, seed=2)
+    for lanes in (16, 32, 64):
+        got, ref, _ = run_case(sdb, odb, seq, roff, "direct", lanes)
+    assert (got.n_rows > 0).sum() > 150
+
+
+def test_db_validation_errors():
+    sdb = synth.make_db(4, 6, 31, 200, 900, seed=1)
+    bad = sdb.branch_ids.copy()
+    bad[1] = bad[0]                                      # repeated branch inside a row
+    with pytest.raises(ra.RkError):
+        ra.PhyloKmerDB(4, 6, 31, sdb.thr_log10, sdb.thr, sdb.key_codes, sdb.row_offsets, bad, sdb.scores)
+    bad = sdb.branch_ids.copy()
+    bad[5] = 31                                          # >= n_branches
+    with pytest.raises(ra.RkError):
+        ra.PhyloKmerDB(4, 6, 31, sdb.thr_log10, sdb.thr, sdb.key_codes, sdb.row_offsets, bad, sdb.scores)
+    dup = sdb.key_codes.copy()
+    dup[3] = dup[2]
+    for mode in MODES.values():
+        with pytest.raises(ra.RkError):
+            ra.PhyloKmerDB(4, 6, 31, sdb.thr_log10, sdb.thr, dup, sdb.row_offsets, sdb.branch_ids, sdb.scores, table_mode=mode)
+    nan = sdb.scores.copy()
+    nan[0] = np.nan
+    with pytest.raises(ra.RkError):
+        ra.PhyloKmerDB(4, 6, 31, sdb.thr_log10, sdb.thr, sdb.key_codes, sdb.row_offsets, sdb.branch_ids, nan)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    with pytest.raises(ra.RkError):
+        ra.PlacementProcess(db).processQueries(np.frombuffer(b"ACGTACGT", np.uint8), np.array([0, 8], np.uint64), keepAtMost=17)
+    db.close()
+
+
+def test_device_api_pack_and_place(c2_small):
+    """rk_pack_reads_device + rk_place_packed_device on HBM-resident buffers == host-buffer path == oracle."""
+    import torch
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 5000, 150, seed=21, amb_rate=0.001, var_len=40)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    pp = ra.PlacementProcess(db)
+    d_seq = torch.from_numpy(seq).cuda()
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    packed, lens, flags = pp.pack_reads(d_seq, d_off, 150)
+    ref_packed, ref_lens = synth.pack_reads_numpy(4, seq, off, words_per_read=packed.shape[1])
+    assert (packed.cpu().numpy().view(np.uint32) == ref_packed).all()
+    assert (lens.cpu().numpy().view(np.uint32) == ref_lens).all()
+    out = pp.place_packed(packed, lens=lens, flags_in=flags, seq_ascii=d_seq, seq_off=d_off)
+    torch.cuda.synchronize()
+    got = ra.Placements(out["n_rows"].cpu().numpy(), out["branch"].cpu().numpy().view(np.uint16), out["score"].cpu().numpy(),
+                        out["lwr"].cpu().numpy(), out["flags"].cpu().numpy().view(np.uint32), {})
+    compare_with_oracle(got, odb.place(seq, off), odb, seq, off)
+    host = pp.processQueries(seq, off)
+    for f in ("n_rows", "branch", "flags"):
+        assert (getattr(host, f) == getattr(got, f)).all()
+    assert (host.score.view(np.uint32) == got.score.view(np.uint32)).all() and (host.lwr == got.lwr).all()
+    db.close()
