@@ -424,10 +424,20 @@ static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, 
 }
 
 template <int BITS, bool DIRECT>
-static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, const AmbArgs &m, hipStream_t stream) {
-    const size_t lds = (size_t)args.s_stride * 12 + (size_t)ASCII_LIST_CAP * 8;
-    if (lds > db->lds_per_cu)
-        return fail(RK_ERR_UNSUPPORTED, "ambiguity path keeps 3 per-branch vectors in LDS: n_branches=%u needs %zu B > %zu B", db->info.n_branches, lds, db->lds_per_cu);
+static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hipStream_t stream) {
+    // LDS: S[s_stride] + candidate list + Samb/Camb windows of `chunk` branches (several passes if the tree is large)
+    const size_t fixed = (size_t)args.s_stride * 4 + (size_t)ASCII_LIST_CAP * 8;
+    if (fixed + 8 * 64 > db->lds_per_cu)
+        return fail(RK_ERR_UNSUPPORTED, "n_branches=%u: the score vector does not fit one CU's LDS (%zu B)", db->info.n_branches, db->lds_per_cu);
+    size_t chunk = args.s_stride;
+    const size_t budget = 64 * 1024;  // prefer several waves per CU; grow only if a single pass would not fit
+    if (fixed + 8 * chunk > budget) {
+        size_t avail = (fixed + 8 * 64 <= budget ? budget : db->lds_per_cu) - fixed;
+        chunk = avail / 8;
+        if (chunk > args.s_stride) chunk = args.s_stride;
+    }
+    m.amb_chunk = (uint32_t)chunk;
+    const size_t lds = fixed + 8 * chunk;
     const uint64_t groups = (args.n_reads + 63) / 64;
     uint64_t waves_cu = db->lds_per_cu / lds;
     if (waves_cu > 32) waves_cu = 32;

@@ -478,6 +478,7 @@ struct AmbArgs {
     const unsigned char *alt_count;   // [16]
     u32 amb_mode;
     u32 max_amb;
+    u32 amb_chunk;  // branches covered by the LDS Samb/Camb windows per pass (== s_stride when everything fits)
 };
 
 template <int BITS, bool DIRECT>
@@ -495,12 +496,15 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     const u32 lane = threadIdx.x & 63;
     const u32 nb = a.db.n_branches;
     u32 *S = lds;
-    float *Samb = (float *)(lds + a.s_stride);
-    u32 *Camb = lds + 2 * a.s_stride;
-    u64 *clist = (u64 *)(lds + 3 * a.s_stride);  // ASCII_LIST_CAP candidate slots for select_topk
+    // Samb/Camb cover branches [lo, lo + amb_chunk) per pass; large trees take several passes over the alternatives
+    const u32 chunk = m.amb_chunk;
+    u64 *clist = (u64 *)(lds + a.s_stride);  // ASCII_LIST_CAP candidate slots for select_topk
+    float *Samb = (float *)(lds + a.s_stride + 2 * ASCII_LIST_CAP);
+    u32 *Camb = lds + a.s_stride + 2 * ASCII_LIST_CAP + chunk;
     const u32 k = a.db.k;
     const float T = a.db.T, P = a.db.P;
-    for (u32 i = lane; i < a.s_stride; i += 64) { S[i] = S_UNTOUCHED; Samb[i] = 0.0f; Camb[i] = 0; }
+    for (u32 i = lane; i < a.s_stride; i += 64) S[i] = S_UNTOUCHED;
+    for (u32 i = lane; i < chunk; i += 64) { Samb[i] = 0.0f; Camb[i] = 0; }
     wave_lds_fence();
     const u64 kmask = (k * BITS >= 64) ? ~0ull : ((1ull << (k * BITS)) - 1);
 
@@ -544,6 +548,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     const u32 p = __builtin_ctz(ambmask);
                     const u32 cls = m.char_table[s[j + p]] & 0x7F;
                     const u32 W = m.alt_count[cls];
+                    for (u32 lo = 0; lo < nb; lo += chunk) {
                     // pass 1: gather alternatives into Samb / Camb (sequential over alternatives)
                     for (u32 w = 0; w < W; w++) {
                         u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
@@ -554,7 +559,8 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         const unsigned short *bp = (const unsigned short *)pr;
                         const float *sp = (const float *)(pr + (((len + 1) & ~1u) << 1));
                         for (u32 e = lane; e < len; e += 64) {
-                            u32 x = bp[e];
+                            const u32 x = (u32)bp[e] - lo;
+                            if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around)
                             float v = sp[e];
                             u32 c = Camb[x];
                             Camb[x] = c + 1;
@@ -577,10 +583,12 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         if (!len) continue;
                         const unsigned short *bp = (const unsigned short *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
-                            u32 x = bp[e];
+                            const u32 xb = bp[e];
+                            const u32 x = xb - lo;
+                            if (x >= chunk) continue;
                             u32 c = Camb[x];
                             if (c != 0) {
-                                u32 old = S[x];
+                                u32 old = S[xb];
                                 float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
                                 float nw;
                                 if (m.amb_mode == RK_AMB_MEAN) {
@@ -593,13 +601,14 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                                     float d = Samb[x] - T;  // :1230
                                     nw = base + d;
                                 }
-                                S[x] = __float_as_uint(nw);
+                                S[xb] = __float_as_uint(nw);
                                 Camb[x] = 0;
                                 Samb[x] = 0.0f;
                             }
                         }
                         wave_lds_fence();
                     }
+                    }  // branch-range passes
                 }
                 // slide
                 code >>= BITS;

@@ -87,6 +87,15 @@ def test_c5_large_tree_scaled(table):
     assert st["placed"] > 300
 
 
+@pytest.mark.parametrize("amb", ["mean", "max"])
+def test_large_tree_ambiguity_multipass(amb):
+    """19 999 branches: the ambiguity kernel's Samb/Camb windows cover the tree in several branch-range passes."""
+    sdb = synth.make_db(4, 7, 19999, 12_000, 2_400_000, seed=8)          # mean row 200
+    seq, off = synth.make_reads(4, 60, 120, seed=13, amb_rate=0.02)
+    got, _, _ = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, amb=amb)
+    assert (got.flags & ra.RK_FLAG_AMBIGUOUS).sum() > 30
+
+
 @pytest.mark.parametrize("amb", ["mean", "max", "skip"])
 @pytest.mark.parametrize("alphabet,cfg", [(4, "C1"), (20, "C4")])
 def test_ambiguity_bad_and_ragged_reads(alphabet, cfg, amb):
@@ -157,7 +166,9 @@ def test_keep_at_most_and_keep_factor(c2_small, K, kf):
 def test_ns_bound_gate(c2_small):
     sdb, odb = c2_small
     seq, off = synth.make_reads(4, 800, 150, seed=5)
-    got, ref, _ = run_case(sdb, odb, seq, off, ns_bound=-575.0)
+    base = odb.place(seq, off)
+    bound = float(np.median(base["score"][:, 0]))          # gate roughly half of the reads
+    got, ref, _ = run_case(sdb, odb, seq, off, ns_bound=bound)
     gated = (got.flags & ra.RK_FLAG_BELOW_NSBOUND) != 0
     assert gated.any() and not gated.all()
     assert (got.n_rows[gated] == 0).all()
