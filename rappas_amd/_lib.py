@@ -65,7 +65,8 @@ EXPORTS = {
 
 
 def lib_path():
-    return _build.ENGINE_SO
+    # RK_LIB: developer override (timing-only ablation builds); the default is the in-tree product library
+    return os.environ.get("RK_LIB") or _build.ENGINE_SO
 
 
 def load():

@@ -13,11 +13,14 @@ typedef unsigned int u32;
 constexpr int DESC_LEN_BITS = 24;
 constexpr u32 DESC_LEN_MASK = (1u << DESC_LEN_BITS) - 1;
 
-// Row image in the blob (8-byte aligned): u16 branch[len] (padded to 4 B) | f32 score[len] | pad to 8 B.
-__host__ __device__ inline u64 row_bytes(u64 len) {
-    u64 b = ((len + 1) & ~1ull) * 2 + len * 4;
-    return (b + 7) & ~7ull;
-}
+// Row image in the blob: len entries of 8 bytes {u32 branch id (16 bits used), f32 score}, 8-byte aligned.
+// One dwordx2 load per lane fetches an entry; chunk c of a row simply starts G entries further.
+// (Algorithmic size of an entry is 6 bytes -- u16 + f32 -- that is what the roofline accounting uses.)
+struct __attribute__((aligned(8))) Entry {
+    u32 branch;
+    float score;
+};
+__host__ __device__ inline u64 row_bytes(u64 len) { return len * 8; }
 
 // Untouched marker for the per-read LDS score vector (a NaN pattern no finite sum can produce).
 constexpr u32 S_UNTOUCHED = 0xFFFFFFFFu;

@@ -14,6 +14,10 @@
 
 using namespace rk;
 
+#ifndef RK_RING
+#define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
@@ -194,14 +198,13 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     }
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
     std::vector<unsigned char> blob;
-    try { blob.assign(blob_bytes, 0); memset(blob.data(), 0xFF, 8); /* reserved: reads as branch 0xFFFF = skip */ } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
+    try { blob.assign(blob_bytes, 0); { Entry skip{0xFFFFu, 0.0f}; memcpy(blob.data(), &skip, 8); } /* reserved entry 0: branch 0xFFFF = skip */ } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
     {
         std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
         for (uint64_t r = 0; r < n_keys; r++) {
             uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
             unsigned char *p = blob.data() + ((desc[r] >> DESC_LEN_BITS) << 3);
-            uint16_t *bp = (uint16_t *)p;
-            float *sp = (float *)(p + (((len + 1) & ~1ull) << 1));
+            Entry *ep = (Entry *)p;
             for (uint64_t i = 0; i < len; i++) {
                 uint16_t x = d->branch_ids[b + i];
                 float v = d->scores[b + i];
@@ -209,8 +212,8 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
                 if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
                 stamp[x] = (uint32_t)r;
                 if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
-                bp[i] = x;
-                sp[i] = v;
+                ep[i].branch = x;
+                ep[i].score = v;
             }
         }
     }
@@ -385,7 +388,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
 template <int G, int BITS, bool DIRECT, bool WIDE>
 static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
     constexpr int PU = G <= 16 ? 4 : (G == 32 ? 2 : 1);
-    constexpr int U = 8;
+    constexpr int U = RK_RING;
     auto kern = place_packed_kernel<G, BITS, DIRECT, WIDE, U, PU>;
     const uint32_t wpb = db->waves_per_block;
     const size_t lds = g.lds_per_wave * wpb;
@@ -471,9 +474,9 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     rk_db *m = const_cast<rk_db *>(db);
     if (choose_geometry(db, 7, g) != RK_OK) return "";
     char buf[160];
-    snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=8,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
+    snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
              g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : "HASH",
-             db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
+             db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();
 }

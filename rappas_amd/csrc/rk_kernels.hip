@@ -18,6 +18,12 @@
 //     K rounds of group arg-max, LWR in fp64 on the first K lanes; the scan also resets S for the next read.
 // No MFMA: this is a gather/accumulate bounded by the memory system, not a contraction.
 #include "rk_device.h"
+#ifndef RK_ROW_NT
+#define RK_ROW_NT 0
+#endif
+#ifndef RK_ABLATE
+#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR (outputs are then wrong)
+#endif
 #include "../../include/rappas_place.h"
 
 namespace rk {
@@ -125,17 +131,16 @@ struct Cursor {
     typedef typename OffsetT<WIDE>::type off_t;
     int h;      // index of the current row in the hit list
     int rem;    // entries of the current row not yet issued (<= 0: fetch the next row)
-    off_t boff; // byte offset of the next branch-id chunk
-    off_t soff; // byte offset of the next score chunk
+    off_t cur;  // byte offset of the next chunk of the current row
     u64 dn;     // list[min(h + 1, cnt)], fetched one step ahead so its LDS latency is off the critical path
 };
 
-// Branch-free on purpose: every lane always issues its two row loads (lanes without an entry read the reserved
-// 8 bytes at blob offset 0, which hold branch id 0xFFFF = "skip"), and nothing selects on a loaded value here,
-// so the compiler counts outstanding loads exactly (s_waitcnt vmcnt(N)) and the register ring keeps U chunks
-// in flight per lane.  list[cnt] must be a zero descriptor (sentinel).
+// Branch-free on purpose: every lane always issues its row load (lanes without an entry read the reserved entry
+// at blob offset 0, whose branch id 0xFFFF means "skip"), and nothing selects on a loaded value here, so the
+// compiler counts outstanding loads exactly (s_waitcnt vmcnt(N)) and the register ring keeps U chunks in flight
+// per lane.  list[cnt] must be a zero descriptor (sentinel).
 template <int G, bool WIDE>
-__device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, int cnt, u32 li2, u32 li4, int li,
+__device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, int cnt, u32 li8, int li,
                                              const unsigned char *rows, u32 &br, float &sc) {
     typedef typename OffsetT<WIDE>::type off_t;
     const bool need = c.rem <= 0;
@@ -148,22 +153,31 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
     const off_t off = (off_t)(d >> DESC_LEN_BITS) << 3;
     c.h = hn;
     c.rem = need ? (int)len : c.rem;
-    c.boff = need ? off : c.boff;
-    c.soff = need ? (off_t)(off + (((len + 1) & ~1u) << 1)) : c.soff;
+    c.cur = need ? off : c.cur;
     const bool ok = li < c.rem;
-    const off_t bo = ok ? (off_t)(c.boff + li2) : (off_t)0;
-    const off_t so = ok ? (off_t)(c.soff + li4) : (off_t)0;
-    br = *(const unsigned short *)(rows + bo);
-    sc = *(const float *)(rows + so);
+    off_t eo = ok ? (off_t)(c.cur + li8) : (off_t)0;
+    if (RK_ABLATE & 16) eo = 0;  // timing-only: every row load reads the reserved "skip" entry
+#if RK_ROW_NT
+    const u64 ev = __builtin_nontemporal_load((const u64 *)(rows + eo));  // rows are read once: do not keep them in L2
+    br = (u32)ev;
+    sc = __uint_as_float((u32)(ev >> 32));
+#else
+    const uint2 e = *(const uint2 *)(rows + eo);
+    br = e.x;
+    sc = __uint_as_float(e.y);
+#endif
     c.rem -= G;
-    c.boff += 2 * G;
-    c.soff += 4 * G;
+    c.cur += 8 * G;
 }
 
 // S[x] update of PlacementProcess.java:726-733: first touch seeds fl(Q*T), then S = fl(S + fl(v - T)).
 // Branch-free: lanes without an entry (br == 0xFFFF) update the group's scratch word S[nb] instead, so the
 // compiler can overlap the LDS read latency with the address arithmetic of the next ring slot.
 __device__ __forceinline__ void apply_entry(u32 *S, u32 nb, u32 br, float sc, float QT, float T) {
+    if (RK_ABLATE & 8) {  // timing-only: keep the loads alive, skip the LDS update
+        asm volatile("" ::"v"(br), "v"(sc));
+        return;
+    }
     const u32 idx = (br != 0xFFFFu) ? br : nb;
     const u32 old = S[idx];
     const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
@@ -183,18 +197,18 @@ template <int G, int U, bool WIDE>
 __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list, int cnt, u32 li,
                                                 const unsigned char *rows, float QT, float T) {
     Cursor<WIDE> c;
-    c.h = -1; c.rem = 0; c.boff = 0; c.soff = 0;
+    c.h = -1; c.rem = 0; c.cur = 0;
     c.dn = list[0];
-    const u32 li2 = li * 2, li4 = li * 4;
+    const u32 li8 = li * 8;
     u32 br[U];
     float sc[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) cursor_issue<G, WIDE>(c, list, cnt, li2, li4, (int)li, rows, br[u], sc[u]);
+    for (int u = 0; u < U; u++) cursor_issue<G, WIDE>(c, list, cnt, li8, (int)li, rows, br[u], sc[u]);
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             apply_entry(S, nb, br[u], sc[u], QT, T);
-            cursor_issue<G, WIDE>(c, list, cnt, li2, li4, (int)li, rows, br[u], sc[u]);
+            cursor_issue<G, WIDE>(c, list, cnt, li8, (int)li, rows, br[u], sc[u]);
         }
         if (!__any(c.h < cnt)) break;
     }
@@ -295,7 +309,7 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
     u32 branch = 0xFFFFu - (u32)(win_key & 0xFFFFu);
     int n_rows = 0;
     double lwr = 0.0;
-    if (numBest > 0) {
+    if (numBest > 0 && !(RK_ABLATE & 4)) {
         flags |= RK_FLAG_PLACED;
         float best = __shfl(score, 0, G);
         float lowest = __shfl(score, numBest - 1, G);
@@ -451,13 +465,15 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
             if (li == 0) list[cnt] = 0;  // sentinel: an empty row ends the cursor
             wave_lds_fence();
             // ---- accumulate in k-mer order ----
-            if (__any(cnt > 0)) accumulate_list<G, U, WIDE>(S, nb, list, cnt, li, a.db.rows, QT, T);
+            if (!(RK_ABLATE & 1) && __any(cnt > 0)) accumulate_list<G, U, WIDE>(S, nb, list, cnt, li, a.db.rows, QT, T);
             wave_lds_fence();
         }
 
         // ---- select + weigh + store (also resets S) ----
         u64 win_key;
-        int numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
+        int numBest = 0;
+        if (RK_ABLATE & 2) { win_key = list[0]; for (u32 i = li; i < nb; i += G) S[i] = S_UNTOUCHED; }
+        else numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
         wave_lds_fence();
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
@@ -484,10 +500,8 @@ struct AmbArgs {
 template <int BITS, bool DIRECT>
 __device__ __forceinline__ void amb_apply_plain(const DbView &db, u32 *S, u64 desc, u32 lane, float QT, float T) {
     u32 len = (u32)desc & DESC_LEN_MASK;
-    const unsigned char *p = db.rows + ((desc >> DESC_LEN_BITS) << 3);
-    const unsigned short *bp = (const unsigned short *)p;
-    const float *sp = (const float *)(p + (((len + 1) & ~1u) << 1));
-    for (u32 e = lane; e < len; e += 64) apply_entry_masked(S, bp[e], sp[e], QT, T);
+    const Entry *ep = (const Entry *)(db.rows + ((desc >> DESC_LEN_BITS) << 3));
+    for (u32 e = lane; e < len; e += 64) apply_entry_masked(S, ep[e].branch, ep[e].score, QT, T);
 }
 
 template <int BITS, bool DIRECT>
@@ -555,13 +569,11 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         u64 desc = lookup_desc<BITS, DIRECT>(a.db, cw);
                         u32 len = (u32)desc & DESC_LEN_MASK;
                         if (!len) continue;
-                        const unsigned char *pr = a.db.rows + ((desc >> DESC_LEN_BITS) << 3);
-                        const unsigned short *bp = (const unsigned short *)pr;
-                        const float *sp = (const float *)(pr + (((len + 1) & ~1u) << 1));
+                        const Entry *ep = (const Entry *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
-                            const u32 x = (u32)bp[e] - lo;
+                            const u32 x = ep[e].branch - lo;
                             if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around)
-                            float v = sp[e];
+                            float v = ep[e].score;
                             u32 c = Camb[x];
                             Camb[x] = c + 1;
                             if (m.amb_mode == RK_AMB_MEAN) {
@@ -581,9 +593,9 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         u64 desc = lookup_desc<BITS, DIRECT>(a.db, cw);
                         u32 len = (u32)desc & DESC_LEN_MASK;
                         if (!len) continue;
-                        const unsigned short *bp = (const unsigned short *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
+                        const Entry *ep = (const Entry *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
-                            const u32 xb = bp[e];
+                            const u32 xb = ep[e].branch;
                             const u32 x = xb - lo;
                             if (x >= chunk) continue;
                             u32 c = Camb[x];
