@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5mini"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's count)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per read (0=auto, 8/16/32/64)")
-    ap.add_argument("--table", default="auto", choices=["auto", "direct", "hash"])
+    ap.add_argument("--table", default="auto", choices=["auto", "direct", "direct8", "hash"])
     ap.add_argument("--verify", type=int, default=2000, help="reads checked against the oracle before timing")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,7 +118,7 @@ def main():
     alphabet, k, leaves, n_keys, n_entries, rlen, n_reads_cfg = synth.CONFIGS[a.config]
     n_reads = a.reads or n_reads_cfg
     sdb = synth.make_config_db(a.config, seed=42, scale=a.db_scale)
-    mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "hash": ra.RK_TABLE_HASH}[a.table]
+    mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": ra.RK_TABLE_HASH}[a.table]
     db = ra.PhyloKmerDB.from_synth(sdb, device=local_rank, table_mode=mode)
     if a.lanes:
         db.set_lanes_per_read(a.lanes)
@@ -223,7 +223,7 @@ def main():
             "config": {"workload": f"{a.config}: {'DNA' if alphabet == 4 else 'AA'} k={k}, {sdb.n_branches} branches, "
                                    f"{sdb.n_keys} keys / {sdb.n_entries} entries phylo-kmer DB (seed 42) replicated per GPU, "
                                    f"{n_reads} x {rlen} symbol reads per GPU per step (uniform, seed 1+rank), keep_at_most=7",
-                       "table": "direct" if db.info.table_mode == ra.RK_TABLE_DIRECT else "hash",
+                       "table": {ra.RK_TABLE_DIRECT: "direct (compact 2 B/k-mer blocks)", ra.RK_TABLE_DIRECT8: "direct8", ra.RK_TABLE_HASH: "hash"}[db.info.table_mode],
                        "kernel": db.kernel_name(), "reads_per_gpu": n_reads, "sharding": f"reads x{n_gpus}, DB replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "bytes_per_read": B, "entries_per_read": H_mean,

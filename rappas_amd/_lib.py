@@ -8,7 +8,7 @@ _LIB = None
 
 RK_ALPHABET_DNA, RK_ALPHABET_AA = 4, 20
 RK_AMB_SKIP, RK_AMB_MEAN, RK_AMB_MAX = 0, 1, 2
-RK_TABLE_AUTO, RK_TABLE_HASH, RK_TABLE_DIRECT = 0, 1, 2
+RK_TABLE_AUTO, RK_TABLE_HASH, RK_TABLE_DIRECT, RK_TABLE_DIRECT8 = 0, 1, 2, 4
 RK_FLAG_PLACED, RK_FLAG_BAD_CHAR, RK_FLAG_TOO_SHORT, RK_FLAG_AMBIGUOUS, RK_FLAG_BELOW_NSBOUND, RK_FLAG_TOO_LONG = 1, 2, 4, 8, 16, 64
 RK_OK, RK_ERR_INVALID, RK_ERR_NO_DEVICE, RK_ERR_HIP, RK_ERR_NOMEM, RK_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 

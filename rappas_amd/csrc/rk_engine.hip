@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -176,51 +177,19 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     uint64_t space = 0;
     const bool space_ok = ipow_fits(d->alphabet, d->k, 1ull << 40, space);
     uint32_t mode = d->table_mode;
-    if (mode == RK_TABLE_AUTO) mode = (space_ok && space <= (1ull << 28)) ? RK_TABLE_DIRECT : RK_TABLE_HASH;
-    if (mode == RK_TABLE_DIRECT && !(space_ok && space <= (1ull << 31)))
+    bool auto_mode = false;
+    if (mode == RK_TABLE_AUTO) {
+        // measured on C2 (profiles/): the 8-byte-descriptor table is ~4 % faster than the compact one while it is small
+        // (8 MiB at k=10); beyond 32 MiB the compact blocks (2 B per k-mer) keep the lookups in L2 / Infinity Cache.
+        auto_mode = true;
+        mode = !(space_ok && space <= (1ull << 28)) ? RK_TABLE_HASH : (space * 8 <= (32ull << 20) ? RK_TABLE_DIRECT8 : RK_TABLE_DIRECT);
+    }
+    if ((mode == RK_TABLE_DIRECT || mode == RK_TABLE_DIRECT8) && !(space_ok && space <= (1ull << 31)))
         return fail(RK_ERR_UNSUPPORTED, "rk_db_create: direct table needs sigma^k <= 2^31 slots");
-    if (mode != RK_TABLE_DIRECT && mode != RK_TABLE_HASH) return fail(RK_ERR_INVALID, "rk_db_create: bad table_mode %u", mode);
+    if (mode != RK_TABLE_DIRECT && mode != RK_TABLE_DIRECT8 && mode != RK_TABLE_HASH)
+        return fail(RK_ERR_INVALID, "rk_db_create: bad table_mode %u", mode);
 
-    // ---- validate rows, lay out the row blob ----
-    std::vector<uint64_t> desc(n_keys);
-    uint64_t blob_bytes = 8;  // offset 0 is reserved so that a zero descriptor means "absent"
-    uint32_t max_len = 0;
-    for (uint64_t r = 0; r < n_keys; r++) {
-        uint64_t b = d->row_offsets[r], e = d->row_offsets[r + 1];
-        if (e < b) return fail(RK_ERR_INVALID, "rk_db_create: row_offsets not monotone at key %llu", (unsigned long long)r);
-        uint64_t len = e - b;
-        if (len == 0) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an empty row", (unsigned long long)r);
-        if (len >= (1ull << DESC_LEN_BITS) || len > d->n_branches)
-            return fail(RK_ERR_INVALID, "rk_db_create: row %llu has %llu entries (> n_branches)", (unsigned long long)r, (unsigned long long)len);
-        if (len > max_len) max_len = (uint32_t)len;
-        desc[r] = ((blob_bytes >> 3) << DESC_LEN_BITS) | len;
-        blob_bytes += row_bytes(len);
-    }
-    if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
-    std::vector<unsigned char> blob;
-    try { blob.assign(blob_bytes, 0); { Entry skip{0xFFFFu, 0.0f}; memcpy(blob.data(), &skip, 8); } /* reserved entry 0: branch 0xFFFF = skip */ } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
-    {
-        std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
-        for (uint64_t r = 0; r < n_keys; r++) {
-            uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
-            unsigned char *p = blob.data() + ((desc[r] >> DESC_LEN_BITS) << 3);
-            Entry *ep = (Entry *)p;
-            for (uint64_t i = 0; i < len; i++) {
-                uint16_t x = d->branch_ids[b + i];
-                float v = d->scores[b + i];
-                if (x >= d->n_branches) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u >= n_branches in row %llu", x, (unsigned long long)r);
-                if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
-                stamp[x] = (uint32_t)r;
-                if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
-                ep[i].branch = x;
-                ep[i].score = v;
-            }
-        }
-    }
-
-    // ---- table ----
-    std::vector<uint64_t> table;  // direct: desc per dense index; hash: pairs {key+1, desc}
-    uint64_t slots = 0, hash_mask = 0;
+    // ---- validate keys; rows are laid out in dense-index order of their k-mer ----
     auto code_ok = [&](uint64_t code, uint64_t &dense) -> bool {
         if (bits == 2) {
             if (d->k * 2 < 64 && (code >> (2 * d->k))) return false;
@@ -238,29 +207,99 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
         dense = idx;
         return true;
     };
+    std::vector<std::pair<uint64_t, uint64_t>> order;  // (dense index, key number)
+    try { order.resize(n_keys); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
+    for (uint64_t r = 0; r < n_keys; r++) {
+        uint64_t dense;
+        if (!code_ok(d->key_codes[r], dense)) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an invalid k-mer code", (unsigned long long)r);
+        order[r] = {dense, r};
+    }
+    std::sort(order.begin(), order.end());
+    for (uint64_t i = 1; i < n_keys; i++)
+        if (order[i].first == order[i - 1].first)
+            return fail(RK_ERR_INVALID, "rk_db_create: duplicate k-mer code at key %llu", (unsigned long long)order[i].second);
+
+    // ---- row blob: every row starts on a 64-byte line and is padded to whole lines (8 entries) with "skip"
+    //      entries, so a row of n entries costs exactly ceil(n/8) line requests; line 0 is reserved (all skip) ----
+    std::vector<uint64_t> desc(n_keys);  // by key number
+    uint64_t blob_units = 1;             // 64-byte units
+    uint32_t max_len = 0;
+    uint64_t max_units = 0;
+    for (uint64_t i = 0; i < n_keys; i++) {
+        const uint64_t r = order[i].second;
+        uint64_t b = d->row_offsets[r], e = d->row_offsets[r + 1];
+        if (e < b) return fail(RK_ERR_INVALID, "rk_db_create: row_offsets not monotone at key %llu", (unsigned long long)r);
+        uint64_t len = e - b;
+        if (len == 0) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an empty row", (unsigned long long)r);
+        if (len > d->n_branches)
+            return fail(RK_ERR_INVALID, "rk_db_create: row %llu has %llu entries (> n_branches)", (unsigned long long)r, (unsigned long long)len);
+        if (len > max_len) max_len = (uint32_t)len;
+        const uint64_t units = (len + ROW_UNIT - 1) / ROW_UNIT;
+        if (units > max_units) max_units = units;
+        desc[r] = ((blob_units * 8) << DESC_LEN_BITS) | (units * ROW_UNIT);
+        blob_units += units;
+    }
+    const uint64_t blob_bytes = blob_units * 64;
+    if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
+    std::vector<Entry> blob;
+    try { blob.assign(blob_bytes / 8, Entry{0xFFFFu, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
+    {
+        std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
+        for (uint64_t r = 0; r < n_keys; r++) {
+            uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
+            Entry *ep = blob.data() + (desc[r] >> DESC_LEN_BITS);
+            for (uint64_t i = 0; i < len; i++) {
+                uint16_t x = d->branch_ids[b + i];
+                float v = d->scores[b + i];
+                if (x >= d->n_branches) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u >= n_branches in row %llu", x, (unsigned long long)r);
+                if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
+                stamp[x] = (uint32_t)r;
+                if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
+                ep[i].branch = x;
+                ep[i].score = v;
+            }
+        }
+    }
+
+    // ---- table ----
+    // DIRECT  : compact blocks, 32 bytes per 16 consecutive k-mers {u64 first row unit, 16 x u8 units per row}: 2 bytes
+    //           per k-mer, small enough to live in the XCD L2s; a row's offset is the block base plus a byte prefix sum.
+    //           Needs rows of <= 255 units (2040 entries); otherwise DIRECT falls back to DIRECT8.
+    // DIRECT8 : one 8-byte descriptor per k-mer.
+    // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
+    if (mode == RK_TABLE_DIRECT && max_units > 255) mode = RK_TABLE_DIRECT8;
+    (void)auto_mode;
+    std::vector<uint64_t> table;
+    uint64_t slots = 0, hash_mask = 0;
     try {
         if (mode == RK_TABLE_DIRECT) {
             slots = space;
-            table.assign(slots, 0);
-            for (uint64_t r = 0; r < n_keys; r++) {
-                uint64_t dense;
-                if (!code_ok(d->key_codes[r], dense)) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an invalid k-mer code", (unsigned long long)r);
-                if (table[dense]) return fail(RK_ERR_INVALID, "rk_db_create: duplicate k-mer code at key %llu", (unsigned long long)r);
-                table[dense] = desc[r];
+            const uint64_t n_blocks = (space + 15) / 16;
+            table.assign(n_blocks * 4, 0);
+            unsigned char *tb = (unsigned char *)table.data();
+            uint64_t next_unit = 1, ki = 0;
+            for (uint64_t blk = 0; blk < n_blocks; blk++) {
+                memcpy(tb + blk * 32, &next_unit, 8);
+                while (ki < n_keys && (order[ki].first >> 4) == blk) {
+                    const uint64_t units = ((uint32_t)desc[order[ki].second] & DESC_LEN_MASK) / ROW_UNIT;
+                    tb[blk * 32 + 16 + (order[ki].first & 15)] = (unsigned char)units;
+                    next_unit += units;
+                    ki++;
+                }
             }
+        } else if (mode == RK_TABLE_DIRECT8) {
+            slots = space;
+            table.assign(slots, 0);
+            for (uint64_t i = 0; i < n_keys; i++) table[order[i].first] = desc[order[i].second];
         } else {
             slots = 16;
             while (slots < 2 * n_keys) slots <<= 1;
             hash_mask = slots - 1;
             table.assign(slots * 2, 0);
             for (uint64_t r = 0; r < n_keys; r++) {
-                uint64_t dense, code = d->key_codes[r];
-                if (!code_ok(code, dense)) return fail(RK_ERR_INVALID, "rk_db_create: key %llu has an invalid k-mer code", (unsigned long long)r);
+                const uint64_t code = d->key_codes[r];
                 uint64_t h = host_mix64(code) & hash_mask;
-                while (table[2 * h]) {
-                    if (table[2 * h] == code + 1) return fail(RK_ERR_INVALID, "rk_db_create: duplicate k-mer code at key %llu", (unsigned long long)r);
-                    h = (h + 1) & hash_mask;
-                }
+                while (table[2 * h]) h = (h + 1) & hash_mask;
                 table[2 * h] = code + 1;
                 table[2 * h + 1] = desc[r];
             }
@@ -310,7 +349,8 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     db->info.n_keys = n_keys; db->info.n_entries = n_entries; db->info.table_slots = slots;
     db->info.table_bytes = table_bytes; db->info.rows_bytes = blob_bytes; db->info.bits_per_symbol = bits;
     db->info.max_row_len = max_len;
-    db->view.direct = mode == RK_TABLE_DIRECT ? (const u64 *)db->d_table : nullptr;
+    db->view.direct = mode == RK_TABLE_DIRECT8 ? (const u64 *)db->d_table : nullptr;
+    db->view.compact = mode == RK_TABLE_DIRECT ? (const uint4 *)db->d_table : nullptr;
     db->view.slots = mode == RK_TABLE_HASH ? (const uint4 *)db->d_table : nullptr;
     db->view.hash_mask = hash_mask;
     db->view.rows = (const unsigned char *)db->d_rows;
@@ -385,11 +425,11 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
     return RK_OK;
 }
 
-template <int G, int BITS, bool DIRECT, bool WIDE>
+template <int G, int BITS, int TM, bool WIDE>
 static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
     constexpr int PU = G <= 16 ? 4 : (G == 32 ? 2 : 1);
     constexpr int U = RK_RING;
-    auto kern = place_packed_kernel<G, BITS, DIRECT, WIDE, U, PU>;
+    auto kern = place_packed_kernel<G, BITS, TM, WIDE, U, PU>;
     const uint32_t wpb = db->waves_per_block;
     const size_t lds = g.lds_per_wave * wpb;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -403,15 +443,19 @@ static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &a
     return RK_OK;
 }
 
-template <int G, int BITS, bool DIRECT>
+template <int G, int BITS, int TM>
 static int launch_w(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
     // 32-bit row offsets whenever the row blob is < 4 GiB
-    return db->info.rows_bytes < (1ull << 32) ? launch_variant<G, BITS, DIRECT, false>(db, g, a, s)
-                                              : launch_variant<G, BITS, DIRECT, true>(db, g, a, s);
+    return db->info.rows_bytes < (1ull << 32) ? launch_variant<G, BITS, TM, false>(db, g, a, s)
+                                              : launch_variant<G, BITS, TM, true>(db, g, a, s);
 }
 template <int G, int BITS>
 static int launch_t(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
-    return db->info.table_mode == RK_TABLE_DIRECT ? launch_w<G, BITS, true>(db, g, a, s) : launch_w<G, BITS, false>(db, g, a, s);
+    switch (db->info.table_mode) {
+    case RK_TABLE_DIRECT: return launch_w<G, BITS, TM_COMPACT>(db, g, a, s);
+    case RK_TABLE_DIRECT8: return launch_w<G, BITS, TM_DIRECT8>(db, g, a, s);
+    default: return launch_w<G, BITS, TM_HASH>(db, g, a, s);
+    }
 }
 template <int G>
 static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
@@ -426,7 +470,7 @@ static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, 
     }
 }
 
-template <int BITS, bool DIRECT>
+template <int BITS, int TM>
 static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hipStream_t stream) {
     // LDS: S[s_stride] + candidate list + Samb/Camb windows of `chunk` branches (several passes if the tree is large)
     const size_t fixed = (size_t)args.s_stride * 4 + (size_t)ASCII_LIST_CAP * 8;
@@ -447,7 +491,7 @@ static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hip
     uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
     if (blocks > groups) blocks = groups;
     if (!blocks) return RK_OK;
-    auto kern = place_ascii_kernel<BITS, DIRECT>;
+    auto kern = place_ascii_kernel<BITS, TM>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
     HIP_TRY(hipGetLastError());
@@ -455,9 +499,12 @@ static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hip
 }
 
 static int launch_ascii(const rk_db *db, const PlaceArgs &a, const AmbArgs &m, hipStream_t s) {
-    const bool direct = db->info.table_mode == RK_TABLE_DIRECT;
-    if (db->info.bits_per_symbol == 2) return direct ? launch_ascii_v<2, true>(db, a, m, s) : launch_ascii_v<2, false>(db, a, m, s);
-    return direct ? launch_ascii_v<5, true>(db, a, m, s) : launch_ascii_v<5, false>(db, a, m, s);
+    const bool dna = db->info.bits_per_symbol == 2;
+    switch (db->info.table_mode) {
+    case RK_TABLE_DIRECT: return dna ? launch_ascii_v<2, TM_COMPACT>(db, a, m, s) : launch_ascii_v<5, TM_COMPACT>(db, a, m, s);
+    case RK_TABLE_DIRECT8: return dna ? launch_ascii_v<2, TM_DIRECT8>(db, a, m, s) : launch_ascii_v<5, TM_DIRECT8>(db, a, m, s);
+    default: return dna ? launch_ascii_v<2, TM_HASH>(db, a, m, s) : launch_ascii_v<5, TM_HASH>(db, a, m, s);
+    }
 }
 
 static int check_params(const rk_params *p) {
@@ -475,7 +522,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     if (choose_geometry(db, 7, g) != RK_OK) return "";
     char buf[160];
     snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
-             g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : "HASH",
+             g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
              db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();

@@ -101,9 +101,27 @@ __device__ __forceinline__ u64 dense_index(u64 code, u32 k) {
     return idx;
 }
 
-template <int BITS, bool DIRECT>
+template <int BITS, int TM>
 __device__ __forceinline__ u64 lookup_desc(const DbView &db, u64 code) {
-    if (DIRECT) {
+    if (TM == TM_COMPACT) {
+        // block of 16 consecutive k-mers: {u64 first 64-byte unit of the block's rows, u64 unused, 16 x u8 units per row}
+        const u64 idx = dense_index<BITS>(code, db.k);
+        const u32 i = (u32)idx & 15;
+        const uint4 *blk = db.compact + (idx >> 4) * 2;
+        const uint4 h = blk[0];
+        const uint4 n = blk[1];
+        const u32 w[4] = {n.x, n.y, n.z, n.w};
+        u32 prefix = 0, mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = (int)i - 4 * q;  // bytes of this word that precede k-mer i
+            const u32 m = r >= 4 ? 0xFFFFFFFFu : (r <= 0 ? 0u : ((1u << (8 * r)) - 1u));
+            prefix = __builtin_amdgcn_sad_u8(w[q] & m, 0u, prefix);
+            mine = (r >= 0 && r < 4) ? ((w[q] >> (8 * r)) & 0xFFu) : mine;
+        }
+        const u64 unit = (((u64)h.y << 32) | h.x) + prefix;
+        return mine ? (((unit * ROW_UNIT) << DESC_LEN_BITS) | (u64)(mine * ROW_UNIT)) : 0ull;
+    } else if (TM == TM_DIRECT8) {
         return db.direct[dense_index<BITS>(code, db.k)];
     } else {
         u64 h = mix64(code) & db.hash_mask;
@@ -356,7 +374,7 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
 // ------------------------------------------------------------------------------------------------
 // main placement kernel: reads packed 2-bit / 5-bit, no ambiguity characters
 // ------------------------------------------------------------------------------------------------
-template <int G, int BITS, bool DIRECT, bool WIDE, int U, int PU>
+template <int G, int BITS, int TM, bool WIDE, int U, int PU>
 __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     constexpr int NG = 64 / G;
     extern __shared__ u32 lds[];
@@ -409,16 +427,16 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                 for (int u = 0; u < PU; u++) {
                     const u32 j = pos + u * G + li;
                     const bool okj = more && j < Q;
-                    if (DIRECT) {  // branch-free gather: out-of-range lanes re-read position 0 and drop the result later
+                    if (TM != TM_HASH) {  // branch-free gather: out-of-range lanes re-read position 0 and drop the result later
                         desc[u] = extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k);
                     } else {
                         desc[u] = 0;
-                        if (okj) desc[u] = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                        if (okj) desc[u] = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
                     }
                 }
-                if (DIRECT) {
+                if (TM != TM_HASH) {
 #pragma unroll
-                    for (int u = 0; u < PU; u++) desc[u] = lookup_desc<BITS, DIRECT>(a.db, desc[u]);
+                    for (int u = 0; u < PU; u++) desc[u] = lookup_desc<BITS, TM>(a.db, desc[u]);
 #pragma unroll
                     for (int u = 0; u < PU; u++) {
                         const u32 j = pos + u * G + li;
@@ -448,11 +466,11 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     u64 d = 0;
                     const u32 j = pos + li;
                     const bool okj = more && j < Q;
-                    if (DIRECT) {
-                        u64 dd = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k));
+                    if (TM != TM_HASH) {
+                        u64 dd = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k));
                         d = okj ? dd : 0ull;
                     } else if (okj) {
-                        d = lookup_desc<BITS, DIRECT>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                        d = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
                     }
                     bool hit = ((u32)d & DESC_LEN_MASK) != 0;
                     u64 b = __ballot(hit);
@@ -497,14 +515,17 @@ struct AmbArgs {
     u32 amb_chunk;  // branches covered by the LDS Samb/Camb windows per pass (== s_stride when everything fits)
 };
 
-template <int BITS, bool DIRECT>
+template <int BITS, int TM>
 __device__ __forceinline__ void amb_apply_plain(const DbView &db, u32 *S, u64 desc, u32 lane, float QT, float T) {
     u32 len = (u32)desc & DESC_LEN_MASK;
     const Entry *ep = (const Entry *)(db.rows + ((desc >> DESC_LEN_BITS) << 3));
-    for (u32 e = lane; e < len; e += 64) apply_entry_masked(S, ep[e].branch, ep[e].score, QT, T);
+    for (u32 e = lane; e < len; e += 64) {
+        const Entry en = ep[e];
+        if (en.branch != 0xFFFFu) apply_entry_masked(S, en.branch, en.score, QT, T);  // rows are padded with skip entries
+    }
 }
 
-template <int BITS, bool DIRECT>
+template <int BITS, int TM>
 __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m) {
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
@@ -556,8 +577,8 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                 }
                 const u32 namb = __builtin_popcount(ambmask);
                 if (namb == 0) {
-                    u64 desc = lookup_desc<BITS, DIRECT>(a.db, code);
-                    if ((u32)desc & DESC_LEN_MASK) amb_apply_plain<BITS, DIRECT>(a.db, S, desc, lane, QT, T);
+                    u64 desc = lookup_desc<BITS, TM>(a.db, code);
+                    if ((u32)desc & DESC_LEN_MASK) amb_apply_plain<BITS, TM>(a.db, S, desc, lane, QT, T);
                 } else if (namb <= m.max_amb && namb == 1 && m.amb_mode != RK_AMB_SKIP) {
                     const u32 p = __builtin_ctz(ambmask);
                     const u32 cls = m.char_table[s[j + p]] & 0x7F;
@@ -566,13 +587,13 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     // pass 1: gather alternatives into Samb / Camb (sequential over alternatives)
                     for (u32 w = 0; w < W; w++) {
                         u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
-                        u64 desc = lookup_desc<BITS, DIRECT>(a.db, cw);
+                        u64 desc = lookup_desc<BITS, TM>(a.db, cw);
                         u32 len = (u32)desc & DESC_LEN_MASK;
                         if (!len) continue;
                         const Entry *ep = (const Entry *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
                             const u32 x = ep[e].branch - lo;
-                            if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around)
+                            if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around, and pad entries)
                             float v = ep[e].score;
                             u32 c = Camb[x];
                             Camb[x] = c + 1;
@@ -590,14 +611,14 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     // are independent, so the L_amb visiting order does not change any S[x])
                     for (u32 w = 0; w < W; w++) {
                         u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
-                        u64 desc = lookup_desc<BITS, DIRECT>(a.db, cw);
+                        u64 desc = lookup_desc<BITS, TM>(a.db, cw);
                         u32 len = (u32)desc & DESC_LEN_MASK;
                         if (!len) continue;
                         const Entry *ep = (const Entry *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
                             const u32 xb = ep[e].branch;
                             const u32 x = xb - lo;
-                            if (x >= chunk) continue;
+                            if (x >= chunk) continue;  // also skips pad entries (0xFFFF >= any chunk window)
                             u32 c = Camb[x];
                             if (c != 0) {
                                 u32 old = S[xb];

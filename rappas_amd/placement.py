@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (RK_ALPHABET_AA, RK_ALPHABET_DNA, RK_AMB_MAX, RK_AMB_MEAN, RK_AMB_SKIP, RK_TABLE_AUTO,
-                   RK_TABLE_DIRECT, RK_TABLE_HASH, rk_counters, rk_db_desc, rk_db_info, rk_params, rk_result)
+                   RK_TABLE_DIRECT, RK_TABLE_DIRECT8, RK_TABLE_HASH, rk_counters, rk_db_desc, rk_db_info, rk_params, rk_result)
 
 
 def _ptr(a):

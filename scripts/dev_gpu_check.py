@@ -7,7 +7,7 @@ from rappas_amd import synth
 from oracle import oracle as O
 from tests.util import compare_with_oracle
 
-def run(name, nreads, lanes=(0, 8, 16, 32, 64), modes=(ra.RK_TABLE_DIRECT, ra.RK_TABLE_HASH), scale=1.0, **rk):
+def run(name, nreads, lanes=(0, 8, 16, 32, 64), modes=(ra.RK_TABLE_DIRECT, ra.RK_TABLE_DIRECT8, ra.RK_TABLE_HASH), scale=1.0, **rk):
     alphabet, k, leaves, _, _, rl, _ = synth.CONFIGS[name]
     sdb = synth.make_config_db(name, scale=scale)
     odb = O.OracleDB.from_synth(sdb)

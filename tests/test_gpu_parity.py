@@ -16,7 +16,7 @@ from tests.util import compare_with_oracle
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"direct": ra.RK_TABLE_DIRECT, "hash": ra.RK_TABLE_HASH}
+MODES = {"direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": ra.RK_TABLE_HASH}
 
 
 @pytest.fixture(scope="module")
@@ -42,7 +42,7 @@ def run_case(sdb, odb, seq, off, table="direct", lanes=0, amb="mean", **kw):
         db.close()
 
 
-@pytest.mark.parametrize("table", ["direct", "hash"])
+@pytest.mark.parametrize("table", ["direct", "direct8", "hash"])
 @pytest.mark.parametrize("lanes", [0, 8, 16, 32, 64])
 def test_c1_full(table, lanes):
     """BASELINE config 1: DNA k=8, 99 branches, 1k x 150 bp reads."""
@@ -61,7 +61,7 @@ def test_c2_scaled(c2_small, table, lanes):
     run_case(sdb, odb, seq, off, table, lanes)
 
 
-@pytest.mark.parametrize("table", ["direct", "hash"])
+@pytest.mark.parametrize("table", ["direct", "direct8", "hash"])
 @pytest.mark.parametrize("lanes", [0, 8, 64])
 def test_c4_protein(table, lanes):
     """BASELINE config 4: AA k=5 (5-bit packing), 399 branches, 100 aa reads."""
@@ -120,7 +120,7 @@ def test_golden_vectors(path):
     """Hand-derived vectors (tests/golden/): same inputs through the C ABI."""
     g = GU.load(path)
     codes, off, br, sc = g["csr"]
-    for table in ("direct", "hash"):
+    for table in ("direct", "direct8", "hash"):
         db = ra.PhyloKmerDB(g["alphabet"], g["k"], g["n_branches"], g["T"], g["P"], codes, off, br, sc,
                             table_mode=MODES[table])
         odb = O.OracleDB(g["alphabet"], g["k"], g["n_branches"], g["T"], g["P"], codes, off, br, sc)
@@ -204,6 +204,7 @@ def test_long_reads_and_long_rows():
     for lanes in (0, 8, 16, 32, 64):
         run_case(sdb, odb, seq, off, "direct", lanes)
     run_case(sdb, odb, seq, off, "hash", 0)
+    run_case(sdb, odb, seq, off, "direct8", 0)
 
 
 def test_select_prune_path():
