@@ -1,0 +1,81 @@
+/*
+ * rappas_jni.c -- thin JNI adapter over the C ABI of include/rappas_place.h.
+ *
+ * Java side: class core.algos.NativePlacement.  This file is compiled only when a JDK is
+ * available (JAVA_HOME set): this image has no JVM and no jni.h, so it is written blind and is NOT part of
+ * build()/tests.  Build:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *       rappas_amd/csrc/jni/rappas_jni.c -Lrappas_amd -lrappas_place -o librappas_jni.so
+ */
+#include <jni.h>
+#include <math.h>
+#include <stdint.h>
+#include "rappas_place.h"
+
+static void throw_rk(JNIEnv *env, const char *where) {
+    char msg[640];
+    snprintf(msg, sizeof msg, "%s: %s", where, rk_last_error());
+    jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
+    if (ex) (*env)->ThrowNew(env, ex, msg);
+}
+
+/* long dbCreate(int alphabet, boolean convertUO, int k, int nBranches, float thrLog10, float thr,
+ *               long[] keyCodes, long[] rowOffsets, char[] branchIds, float[] scores, int device)
+ * The Java caller fills the arrays by walking session.hash exactly like SessionNext_v2.saveToJSON
+ * (src/main_v2/SessionNext_v2.java:250-261). */
+JNIEXPORT jlong JNICALL Java_core_algos_NativePlacement_dbCreate(JNIEnv *env, jclass cls, jint alphabet,
+        jboolean convertUO, jint k, jint nBranches, jfloat thrLog10, jfloat thr, jlongArray keyCodes,
+        jlongArray rowOffsets, jcharArray branchIds, jfloatArray scores, jint device) {
+    (void)cls;
+    rk_db_desc d;
+    d.alphabet = (uint32_t)alphabet; d.convert_uo = convertUO ? 1u : 0u; d.k = (uint32_t)k;
+    d.n_branches = (uint32_t)nBranches; d.thr_log10 = thrLog10; d.thr = thr;
+    d.n_keys = (uint64_t)(*env)->GetArrayLength(env, keyCodes);
+    d.device = device; d.table_mode = RK_TABLE_AUTO;
+    jlong *kc = (*env)->GetLongArrayElements(env, keyCodes, NULL);
+    jlong *ro = (*env)->GetLongArrayElements(env, rowOffsets, NULL);
+    jchar *br = (*env)->GetCharArrayElements(env, branchIds, NULL);   /* jchar == uint16: (char)nodeId */
+    jfloat *sc = (*env)->GetFloatArrayElements(env, scores, NULL);
+    d.key_codes = (const uint64_t *)kc; d.row_offsets = (const uint64_t *)ro;
+    d.branch_ids = (const uint16_t *)br; d.scores = sc;
+    rk_db *db = NULL;
+    int rc = rk_db_create(&d, &db);
+    (*env)->ReleaseLongArrayElements(env, keyCodes, kc, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, rowOffsets, ro, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, branchIds, br, JNI_ABORT);
+    (*env)->ReleaseFloatArrayElements(env, scores, sc, JNI_ABORT);
+    if (rc != RK_OK) { throw_rk(env, "rk_db_create"); return 0; }
+    return (jlong)(intptr_t)db;
+}
+
+/* void placeBatch(long db, byte[] seqs, long[] offs, int keepAtMost, float keepFactor, int ambMode, float nsBound,
+ *                 byte[] nRows, char[] branch, float[] score, double[] lwr, int[] flags) */
+JNIEXPORT void JNICALL Java_core_algos_NativePlacement_placeBatch(JNIEnv *env, jclass cls, jlong db, jbyteArray seqs,
+        jlongArray offs, jint keepAtMost, jfloat keepFactor, jint ambMode, jfloat nsBound, jbyteArray nRows,
+        jcharArray branch, jfloatArray score, jdoubleArray lwr, jintArray flags) {
+    (void)cls;
+    rk_params p = {(uint32_t)keepAtMost, keepFactor, (uint32_t)ambMode, nsBound};
+    const uint64_t n = (uint64_t)(*env)->GetArrayLength(env, offs) - 1;
+    jbyte *s = (*env)->GetByteArrayElements(env, seqs, NULL);
+    jlong *o = (*env)->GetLongArrayElements(env, offs, NULL);
+    jbyte *nr = (*env)->GetByteArrayElements(env, nRows, NULL);
+    jchar *b = (*env)->GetCharArrayElements(env, branch, NULL);
+    jfloat *sc = (*env)->GetFloatArrayElements(env, score, NULL);
+    jdouble *w = (*env)->GetDoubleArrayElements(env, lwr, NULL);
+    jint *f = (*env)->GetIntArrayElements(env, flags, NULL);
+    rk_result out = {(uint8_t *)nr, (uint16_t *)b, sc, w, (uint32_t *)f};
+    int rc = rk_place_batch((rk_db *)(intptr_t)db, &p, n, (const uint8_t *)s, (const uint64_t *)o, &out, NULL);
+    (*env)->ReleaseByteArrayElements(env, seqs, s, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, offs, o, JNI_ABORT);
+    (*env)->ReleaseByteArrayElements(env, nRows, nr, 0);
+    (*env)->ReleaseCharArrayElements(env, branch, b, 0);
+    (*env)->ReleaseFloatArrayElements(env, score, sc, 0);
+    (*env)->ReleaseDoubleArrayElements(env, lwr, w, 0);
+    (*env)->ReleaseIntArrayElements(env, flags, f, 0);
+    if (rc != RK_OK) throw_rk(env, "rk_place_batch");
+}
+
+JNIEXPORT void JNICALL Java_core_algos_NativePlacement_dbDestroy(JNIEnv *env, jclass cls, jlong db) {
+    (void)env; (void)cls;
+    rk_db_destroy((rk_db *)(intptr_t)db);
+}
