@@ -422,6 +422,10 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         return fail(RK_ERR_UNSUPPORTED, "n_branches=%u needs %zu B of LDS per read, more than one CU has (%zu B)", nb, g.lds_per_wave, db->lds_per_cu);
     uint32_t w = (uint32_t)(db->lds_per_cu / g.lds_per_wave);
     g.waves_per_cu = w > 32 ? 32 : w;
+    if (const char *e = getenv("RK_WAVES_PER_CU")) {  // developer knob for occupancy experiments
+        uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v < g.waves_per_cu) g.waves_per_cu = v;
+    }
     return RK_OK;
 }
 

@@ -1,22 +1,56 @@
-"""Summarise rocprofv3 CSV output (kernel stats + PMC counters) for the placement kernel."""
-import csv, glob, os, sys, collections
+"""Summarise rocprofv3 CSV output (kernel stats + PMC counters) for the placement kernels.
+usage: prof_summary.py <prof_dir> [<out_prefix>]  -> <out_prefix>_kernel_stats.csv, _pmc_summary.txt, _pmc_traffic.json"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
 out = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else None
+
+
 def rows(pat):
     for f in glob.glob(os.path.join(out, pat), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 yield f, r
-# kernel stats
-for f, r in rows("trace/**/*kernel_stats.csv"):
-    if "place" in r.get("Name", "") or float(r.get("Percentage", 0) or 0) > 2:
-        print("STAT", r.get("Name", "")[:90], "calls", r.get("Calls"), "avg_ns", r.get("AverageNs"), "pct", r.get("Percentage"))
-# counters
+
+
+lines = []
+stats = [r for _, r in rows("trace/**/*kernel_stats.csv")]
+for r in stats:
+    if "rk::" in r.get("Name", "") or float(r.get("Percentage", 0) or 0) > 2:
+        lines.append(f"STAT {r.get('Name', '')[:100]} calls={r.get('Calls')} avg_ns={r.get('AverageNs')} min_ns={r.get('MinNs')} max_ns={r.get('MaxNs')} pct={r.get('Percentage')}")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f, r in rows("pmc*/**/*counter_collection.csv"):
     name = r.get("Kernel_Name", "")
-    if "place" not in name: continue
-    agg[name[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "rk::" not in name:
+        continue
+    agg[name[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    print("KERNEL", k)
+    lines.append("KERNEL " + k)
     for c, v in sorted(d.items()):
-        print(f"   {c:28s} n={len(v)} mean={sum(v)/len(v):.4g}")
+        lines.append(f"   {c:28s} launches={len(v)} mean_per_launch={sum(v)/len(v):.6g}")
+print("\n".join(lines))
+if prefix:
+    if stats:
+        with open(prefix + "_kernel_stats.csv", "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(stats[0].keys()))
+            w.writeheader()
+            w.writerows(stats)
+    with open(prefix + "_pmc_summary.txt", "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    for k, d in agg.items():
+        if "place_packed_kernel" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
+            write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+            meta = json.loads(os.environ.get("PROF_META", "{}"))
+            meta.update({"kernel": k, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+                         "hbm_bytes_per_launch": (fetch + write) * 1024,
+                         "note": "FETCH_SIZE/WRITE_SIZE are in KiB per launch (separate --pmc passes); narrow 8-byte gathers issue "
+                                 "64-byte requests, so the wide-stream x2 correction of MI355X_MICROARCH.md does not apply; the C2 DB "
+                                 "(110 MB) sits in the 256 MB Infinity Cache, whose hits these fabric-side counters include"})
+            with open(prefix + "_pmc_traffic.json", "w") as fh:
+                json.dump(meta, fh, indent=1)
