@@ -60,7 +60,7 @@ struct PlaceArgs {
     u32 *o_flags;
     // geometry
     u32 s_stride;  // u32 words per read score vector in LDS
-    u32 list_cap;  // row descriptors per read hit list in LDS
+    u32 list_cap;  // u64 slots of the per-read hit list in LDS
 };
 
 __device__ __forceinline__ u64 mix64(u64 x) {

@@ -177,12 +177,11 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     uint64_t space = 0;
     const bool space_ok = ipow_fits(d->alphabet, d->k, 1ull << 40, space);
     uint32_t mode = d->table_mode;
-    bool auto_mode = false;
     if (mode == RK_TABLE_AUTO) {
-        // measured on C2 (profiles/): the 8-byte-descriptor table is ~4 % faster than the compact one while it is small
-        // (8 MiB at k=10); beyond 32 MiB the compact blocks (2 B per k-mer) keep the lookups in L2 / Infinity Cache.
-        auto_mode = true;
-        mode = !(space_ok && space <= (1ull << 28)) ? RK_TABLE_HASH : (space * 8 <= (32ull << 20) ? RK_TABLE_DIRECT8 : RK_TABLE_DIRECT);
+        // Direct addressing whenever all sigma^k codes fit 2^28 slots; DIRECT = compact 2-byte-per-k-mer blocks that
+        // stay in the XCD L2s (measured on C2: 2.36e8 reads/s vs 2.18e8 with 8-byte descriptors, whose probes push the
+        // Infinity Fabric to its ~6e10 requests/s ceiling -- scripts/ubench/gather_rate.hip).
+        mode = (space_ok && space <= (1ull << 28)) ? RK_TABLE_DIRECT : RK_TABLE_HASH;
     }
     if ((mode == RK_TABLE_DIRECT || mode == RK_TABLE_DIRECT8) && !(space_ok && space <= (1ull << 31)))
         return fail(RK_ERR_UNSUPPORTED, "rk_db_create: direct table needs sigma^k <= 2^31 slots");
@@ -268,7 +267,6 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     // DIRECT8 : one 8-byte descriptor per k-mer.
     // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
     if (mode == RK_TABLE_DIRECT && max_units > 255) mode = RK_TABLE_DIRECT8;
-    (void)auto_mode;
     std::vector<uint64_t> table;
     uint64_t slots = 0, hash_mask = 0;
     try {
@@ -390,32 +388,34 @@ struct Geometry {
     uint32_t waves_per_cu;
 };
 
-static uint32_t probe_unroll(uint32_t G) { return G <= 16 ? 4 : (G == 32 ? 2 : 1); }
+static uint32_t probe_unroll(uint32_t G) { return G <= 16 ? 9 : (G == 32 ? 5 : 3); }  // PU*G >= 144 positions per batch
 
 static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) {
     const uint32_t nb = db->info.n_branches;
-    const uint32_t s_stride = (nb + 2) & ~1u;  // >= nb + 1: word nb is the scratch slot of apply_entry
+    const uint32_t s_stride = (nb + 4) & ~3u;  // >= nb + 1 (word nb is the scratch slot of apply_entry), multiple of 4 (b128 scans)
     const size_t target = db->lds_per_cu / 8;  // aim for >= 8 waves per CU
-    auto bytes_for = [&](uint32_t G, uint32_t cap) { return (size_t)(64 / G) * ((size_t)s_stride * 4 + (size_t)cap * 8); };
+    const size_t fixed = (size_t)s_stride * 4;  // per read, besides the hit list
+    auto bytes_for = [&](uint32_t G, uint32_t cap) { return (size_t)(64 / G) * (fixed + (size_t)cap * 8); };
     uint32_t G = db->lanes_per_read;
     if (G == 0) {
         G = 64;
         for (uint32_t cand : {16u, 32u, 64u}) {
             if (cand < keep_at_most) continue;
-            if (bytes_for(cand, probe_unroll(cand) * cand + 40) <= target) { G = cand; break; }
+            if (bytes_for(cand, cand + 3 * RK_RING + 40) <= target) { G = cand; break; }
         }
     }
     if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
     const uint32_t NG = 64 / G, pu = probe_unroll(G);
-    const uint32_t min_cap = pu * G + 40;  // probe batch + zero sentinel + 16 winner slots + margin (select_topk)
+    const uint32_t min_cap = G + 3 * RK_RING + 40;  // one sub-batch of rows + sentinel, ring slack, 16 winner slots + margin
     // list capacity: whatever is left of the per-wave LDS target, clamped to [min_cap, 256]
     size_t per_group_target = target / NG;
     uint32_t cap = min_cap;
-    if (per_group_target > (size_t)s_stride * 4 + (size_t)min_cap * 8) {
-        size_t c = (per_group_target - (size_t)s_stride * 4) / 8;
+    if (per_group_target > fixed + (size_t)min_cap * 8) {
+        size_t c = (per_group_target - fixed) / 8;
         cap = (uint32_t)(c > 256 ? 256 : c);
         if (cap < min_cap) cap = min_cap;
     }
+    cap &= ~1u;  // keeps every group's score vector 16-byte aligned
     g.G = G; g.NG = NG; g.s_stride = s_stride; g.list_cap = cap; g.pu = pu;
     g.lds_per_wave = bytes_for(G, cap);
     if (g.lds_per_wave > db->lds_per_cu)
@@ -431,7 +431,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
 
 template <int G, int BITS, int TM, bool WIDE>
 static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
-    constexpr int PU = G <= 16 ? 4 : (G == 32 ? 2 : 1);
+    constexpr int PU = G <= 16 ? 9 : (G == 32 ? 5 : 3);
     constexpr int U = RK_RING;
     auto kern = place_packed_kernel<G, BITS, TM, WIDE, U, PU>;
     const uint32_t wpb = db->waves_per_block;
@@ -527,7 +527,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     char buf[160];
     snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
              g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
-             db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
+             db->info.rows_bytes < (1ull << 32) ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();
 }
@@ -679,3 +679,12 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
     if (counters) *counters = ct;
     return RK_OK;
 }
+
+#ifdef RK_STAMPS
+// diagnostic builds only (scripts/stamps.py)
+extern "C" int rk_debug_read_stamps(unsigned long long *out, int n_waves) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rk::rk_stamp_buf), (size_t)n_waves * 8 * sizeof(unsigned long long)));
+    return RK_OK;
+}
+#endif

@@ -28,6 +28,21 @@
 
 namespace rk {
 
+#ifdef RK_STAMPS
+// Diagnostic build only (scripts/stamps.py): per-wave cycle sums of the kernel phases. Never compiled into the product.
+__device__ unsigned long long rk_stamp_buf[4096 * 8];
+__device__ __forceinline__ unsigned long long rk_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define RK_STAMP(slot) do { unsigned long long n_ = rk_now(); st_[slot] += n_ - t_; t_ = n_; } while (0)
+#else
+#define RK_STAMP(slot) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
@@ -110,15 +125,16 @@ __device__ __forceinline__ u64 lookup_desc(const DbView &db, u64 code) {
         const uint4 *blk = db.compact + (idx >> 4) * 2;
         const uint4 h = blk[0];
         const uint4 n = blk[1];
-        const u32 w[4] = {n.x, n.y, n.z, n.w};
-        u32 prefix = 0, mine = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = (int)i - 4 * q;  // bytes of this word that precede k-mer i
-            const u32 m = r >= 4 ? 0xFFFFFFFFu : (r <= 0 ? 0u : ((1u << (8 * r)) - 1u));
-            prefix = __builtin_amdgcn_sad_u8(w[q] & m, 0u, prefix);
-            mine = (r >= 0 && r < 4) ? ((w[q] >> (8 * r)) & 0xFFu) : mine;
-        }
+        // byte prefix sum of the 16 per-row unit counts: running sums over whole words (v_sad_u8 accumulates),
+        // then the partial word of k-mer i
+        const u32 c0 = __builtin_amdgcn_sad_u8(n.x, 0u, 0u);
+        const u32 c1 = __builtin_amdgcn_sad_u8(n.y, 0u, c0);
+        const u32 c2 = __builtin_amdgcn_sad_u8(n.z, 0u, c1);
+        const u32 word = i >> 2, sh = (i & 3u) * 8u;
+        const u32 wsel = word == 0 ? n.x : (word == 1 ? n.y : (word == 2 ? n.z : n.w));
+        const u32 csel = word == 0 ? 0u : (word == 1 ? c0 : (word == 2 ? c1 : c2));
+        const u32 prefix = __builtin_amdgcn_sad_u8(wsel & ((1u << sh) - 1u), 0u, csel);
+        const u32 mine = (wsel >> sh) & 0xFFu;
         const u64 unit = (((u64)h.y << 32) | h.x) + prefix;
         return mine ? (((unit * ROW_UNIT) << DESC_LEN_BITS) | (u64)(mine * ROW_UNIT)) : 0ull;
     } else if (TM == TM_DIRECT8) {
@@ -235,66 +251,193 @@ __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list,
 }
 
 // ------------------------------------------------------------------------------------------------
+// accumulate, fast form: the hit list holds one item per CHUNK (<= G entries of one row, whole 64-byte lines),
+// written in k-mer order by the probe phase.  A step is then: decode one item, one entry load per lane, one LDS
+// read-modify-write -- no row cursor.  Items are 32-bit when the row blob is < 4 GiB:
+//   (64-byte line index of the chunk) << 4 | (lines in the chunk),   else the 64-bit descriptor format.
+// Items are read one ring-iteration ahead so their LDS latency is hidden; the list region has 3U slots of slack.
+// ------------------------------------------------------------------------------------------------
+template <bool WIDE> struct ItemT { typedef u32 type; };
+template <> struct ItemT<true> { typedef u64 type; };
+
+template <int G, bool WIDE>
+__device__ __forceinline__ typename ItemT<WIDE>::type make_item(u64 off8, u32 n) {
+    if (WIDE) return (typename ItemT<WIDE>::type)((off8 << DESC_LEN_BITS) | n);
+    return (typename ItemT<WIDE>::type)((u32)(off8 >> 3) << 4 | (n >> 3));
+}
+
+template <int G, bool WIDE>
+__device__ __forceinline__ void chunk_issue(typename ItemT<WIDE>::type it, bool in, u32 li, u32 li8,
+                                            const unsigned char *rows, u32 &br, float &sc) {
+    typedef typename OffsetT<WIDE>::type off_t;
+    bool ok;
+    off_t eo;
+    if (WIDE) {
+        const u32 n = (u32)it & DESC_LEN_MASK;
+        ok = in && li < n;
+        eo = (off_t)(((u64)it >> DESC_LEN_BITS) << 3) + li8;
+    } else {
+        ok = in && (li >> 3) < ((u32)it & 15u);
+        eo = (off_t)((((u32)it & ~15u) << 2) + li8);
+    }
+    eo = ok ? eo : (off_t)0;
+    if (RK_ABLATE & 16) eo = 0;
+    const uint2 e = *(const uint2 *)(rows + eo);
+    br = e.x;
+    sc = __uint_as_float(e.y);
+}
+
+template <int G, int U, bool WIDE>
+__device__ __forceinline__ void accumulate_chunks(u32 *S, u32 nb, const typename ItemT<WIDE>::type *items, int cnt,
+                                                  u32 li, const unsigned char *rows, float QT, float T) {
+    typedef typename ItemT<WIDE>::type item_t;
+    const u32 li8 = li * 8;
+    u32 br[U];
+    float sc[U];
+    item_t it[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) chunk_issue<G, WIDE>(items[u], u < cnt, li, li8, rows, br[u], sc[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) it[u] = items[U + u];
+    int s0 = 0;
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            apply_entry(S, nb, br[u], sc[u], QT, T);
+            chunk_issue<G, WIDE>(it[u], s0 + U + u < cnt, li, li8, rows, br[u], sc[u]);
+            it[u] = items[s0 + 2 * U + u];
+        }
+        s0 += U;
+        if (!__any(s0 < cnt)) break;  // what is left in the ring belongs to steps >= cnt of every group: all skips
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // select: top-K + LWR + output (A8/A9: PlacementProcess.java:396-451, :974-1025)
 // Order among candidates is the total order of the packed key: score desc (Float.compare), then branch id asc.
 // ------------------------------------------------------------------------------------------------
-// Exact top-K of list[0..c): every lane ranks the candidates it owns against all others (LDS broadcast reads);
-// rank r < K goes to win[r].  Returns min(c, K).  Keys are unique (they embed the branch id).
+// ---- cross-lane helpers inside a lane group -------------------------------------------------------------------
+// For G == 16 a group is exactly one DPP row: rotations are single VALU moves (no LDS crossbar traffic, no
+// lgkmcnt wait).  Other group widths use ds_bpermute shuffles.
+template <int S>
+__device__ __forceinline__ u32 row_ror32(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + S, 0xF, 0xF, false);  // row_ror:S
+}
+template <int G, int S>
+__device__ __forceinline__ u64 group_rotate(u64 v, u32 li) {  // value of lane (li - S) mod G ... any fixed permutation works
+    if (G == 16) {
+        return ((u64)row_ror32<S>((u32)(v >> 32)) << 32) | row_ror32<S>((u32)v);
+    } else {
+        return shfl64(v, (int)((li + G - S) % G), G);
+    }
+}
+// number of lanes of the group whose key is greater than mine (keys are unique or zero)
+template <int G, int S>
+struct RankAbove {
+    static __device__ __forceinline__ int run(u64 v, u32 li) {
+        return ((group_rotate<G, S>(v, li) > v) ? 1 : 0) + RankAbove<G, S - 1>::run(v, li);
+    }
+};
+template <int G>
+struct RankAbove<G, 0> {
+    static __device__ __forceinline__ int run(u64, u32) { return 0; }
+};
+template <int G>
+__device__ __forceinline__ u64 group_max(u64 v) {
+    if (G == 16) {
+        u64 o;
+        o = ((u64)row_ror32<8>((u32)(v >> 32)) << 32) | row_ror32<8>((u32)v); v = o > v ? o : v;
+        o = ((u64)row_ror32<4>((u32)(v >> 32)) << 32) | row_ror32<4>((u32)v); v = o > v ? o : v;
+        o = ((u64)row_ror32<2>((u32)(v >> 32)) << 32) | row_ror32<2>((u32)v); v = o > v ? o : v;
+        o = ((u64)row_ror32<1>((u32)(v >> 32)) << 32) | row_ror32<1>((u32)v); v = o > v ? o : v;
+        return v;
+    } else {
+#pragma unroll
+        for (int s = 1; s < G; s <<= 1) {
+            u64 o = shfl_xor64(v, s, G);
+            v = o > v ? o : v;
+        }
+        return v;
+    }
+}
+
+// Exact top-K of list[0..c): rank r < K goes to win[r].  Returns min(c, K).  Keys are unique (they embed the
+// branch id).  c <= G (the usual case): one candidate per lane, ranked with lane rotations; otherwise every lane
+// ranks the candidates it owns against all others through LDS broadcast reads.
 template <int G>
 __device__ __forceinline__ int rank_candidates(const u64 *list, int c, u64 *win, int K, u32 li) {
-    for (int j = (int)li; j < c; j += G) {
-        const u64 mine = list[j];
-        int rank = 0;
-        for (int t = 0; t < c; t++) rank += (list[t] > mine) ? 1 : 0;
-        if (rank < K) win[rank] = mine;
+    if (c <= G) {
+        const u64 mine = ((int)li < c) ? list[li] : 0ull;
+        const int rank = RankAbove<G, G - 1>::run(mine, li);
+        if (mine != 0 && rank < K) win[rank] = mine;
+    } else {
+        for (int j = (int)li; j < c; j += G) {
+            const u64 mine = list[j];
+            int rank = 0;
+            for (int t = 0; t < c; t++) rank += (list[t] > mine) ? 1 : 0;
+            if (rank < K) win[rank] = mine;
+        }
     }
     wave_lds_fence();
     return c < K ? c : K;
 }
 
 // Scans S[0..nb) with the G lanes of a group and resets it to UNTOUCHED; leaves the rank-r winner key in lane r.
-//   pass 1  per-lane maximum (float compare; the UNTOUCHED pattern is a NaN and never wins);
+//   pass 1  per-lane maximum, 4 scores per LDS read (float compare; the UNTOUCHED pattern is a NaN and never wins);
 //   tau     the K-th largest of the G lane maxima: at least K scores are >= tau, so it bounds the answer from below;
-//   pass 2  entries with key >= tau are compacted into the (now idle) hit list; if the list fills up it is pruned
-//           to its exact top-K and tau is raised -- correct for any score distribution;
+//   pass 2  entries with key >= tau are compacted into the (now idle) hit list while S is reset, 4 per LDS access;
+//           if the list fills up it is pruned to its exact top-K and tau is raised -- correct for any distribution;
 //   rank    exact top-K of the few survivors.
-// `list` has `cap` u64 slots; the last 16 are the winners' scratch.  Returns numBest (group-uniform).
+// `list` has `cap` u64 slots; the last 16 are the winners' scratch.  S must be 16-byte aligned with s_stride % 4 == 0
+// (slots in [nb, s_stride) are scratch).  Returns numBest (group-uniform).
 template <int G>
-__device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+__device__ __forceinline__ int select_topk_scan(u32 *S, u32 nb, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     u64 *win = list + (cap - 16);
     const int capc = cap - 16;
+    const uint4 *S4 = (const uint4 *)S;
+    uint4 *S4w = (uint4 *)S;
+    const u32 n4 = (nb + 3) / 4;
     // ---- pass 1 ----
     float mo = -INFINITY;
     u32 mi = 0xFFFFu;
-    for (u32 i = li; i < nb; i += G) {
-        const float v = __uint_as_float(S[i]);
-        const bool gt = v > mo;  // false for the NaN marker; ties keep the smaller branch id
-        mo = gt ? v : mo;
-        mi = gt ? i : mi;
+    for (u32 q = li; q < n4; q += G) {
+        const uint4 v4 = S4[q];
+        const u32 i = 4 * q;
+        const float v[4] = {__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool gt = (v[e] > mo) && (i + e < nb);  // false for the NaN marker; ties keep the smaller branch id
+            mo = gt ? v[e] : mo;
+            mi = gt ? i + e : mi;
+        }
     }
     const u64 km = (mi != 0xFFFFu) ? make_key(__float_as_uint(mo), mi) : 0ull;
     // ---- tau = K-th largest lane maximum (0 if fewer than K lanes saw anything) ----
-    int rank = 0;
-#pragma unroll
-    for (int s = 1; s < G; s++) rank += (shfl_xor64(km, s, G) > km) ? 1 : 0;
-    u64 tau = (rank == K - 1) ? km : 0ull;
-#pragma unroll
-    for (int s = 1; s < G; s <<= 1) {
-        u64 o = shfl_xor64(tau, s, G);
-        tau = o > tau ? o : tau;
-    }
+    const int rank = RankAbove<G, G - 1>::run(km, li);
+    u64 tau = group_max<G>((rank == K - 1) ? km : 0ull);
     // ---- pass 2 ----
     int c = 0;
-    for (u32 i0 = 0; i0 < nb; i0 += G) {
-        const u32 i = i0 + li;
-        u32 raw = S_UNTOUCHED;
-        if (i < nb) { raw = S[i]; S[i] = S_UNTOUCHED; }
-        const u64 key = (raw != S_UNTOUCHED) ? make_key(raw, i) : 0ull;
-        const bool cand = key != 0 && key >= tau;
-        const u64 b = __ballot(cand);
-        const u64 sub = (b >> (gi * G)) & gmask;
-        if (sub) {  // group-uniform
+    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
+    for (u32 q0 = 0; q0 < n4; q0 += G) {
+        const u32 q = q0 + li;
+        uint4 v4 = reset4;
+        if (q < n4) { v4 = S4[q]; S4w[q] = reset4; }
+        const u32 i = 4 * q;
+        const u32 raw[4] = {v4.x, v4.y, v4.z, v4.w};
+        u64 key[4];
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            key[e] = (raw[e] != S_UNTOUCHED && i + e < nb) ? make_key(raw[e], i + e) : 0ull;
+            any = any || (key[e] != 0 && key[e] >= tau);
+        }
+        if (((__ballot(any) >> (gi * G)) & gmask) == 0) continue;  // group-uniform: no candidate in these 4G entries
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool cand = key[e] != 0 && key[e] >= tau;
+            const u64 sub = (__ballot(cand) >> (gi * G)) & gmask;
+            if (sub == 0) continue;
             if (c + G > capc) {  // prune: keep the exact top-K, raise tau
                 wave_lds_fence();
                 const int kept = rank_candidates<G>(list, c, win, K, li);
@@ -303,10 +446,9 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K
                 wave_lds_fence();
                 c = kept;
             }
-            const bool still = cand && key >= tau;
-            const u64 b2 = __ballot(still);
-            const u64 sub2 = (b2 >> (gi * G)) & gmask;
-            if (still) list[c + __builtin_popcountll(sub2 & ((1ull << li) - 1))] = key;
+            const bool still = cand && key[e] >= tau;
+            const u64 sub2 = (__ballot(still) >> (gi * G)) & gmask;
+            if (still) list[c + __builtin_popcountll(sub2 & ((1ull << li) - 1))] = key[e];
             c += __builtin_popcountll(sub2);
         }
     }
@@ -314,6 +456,62 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K
     const int num = rank_candidates<G>(list, c, win, K, li);
     win_key = ((int)li < num) ? win[li] : 0ull;
     wave_lds_fence();
+    return num;
+}
+
+// Fast select: ONE pass over S.  Every lane keeps its three best (score, branch) pairs in registers plus the best
+// score it had to drop; K rounds of group-max over the lane heads then give the exact top-K unless some lane might
+// still hide a better entry (it dropped something >= the K-th winner) -- rare (a lane would need >= 4 of the top K);
+// then the exact two-pass scan above runs instead.  S is reset with plain 16-byte stores afterwards.
+template <int G>
+__device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+    if (K > 8) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key);
+    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    const uint4 *S4 = (const uint4 *)S;
+    uint4 *S4w = (uint4 *)S;
+    const u32 n4 = (nb + 3) / 4;
+    float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
+    u32 i0 = 0xFFFFu, i1 = 0xFFFFu, i2 = 0xFFFFu;
+    for (u32 q = li; q < n4; q += G) {
+        const uint4 v4 = S4[q];
+        const u32 i = 4 * q;
+        const float v[4] = {__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool in = i + e < nb;
+            // strict '>' keeps the smaller branch id ahead among equal scores; NaN (untouched) compares false
+            const bool g0 = in && v[e] > s0, g1 = in && v[e] > s1, g2 = in && v[e] > s2;
+            const float drop = g2 ? s2 : (in ? v[e] : -INFINITY);
+            lost = fmaxf(lost, drop);  // fmaxf ignores the NaN marker
+            s2 = g1 ? s1 : (g2 ? v[e] : s2);
+            i2 = g1 ? i1 : (g2 ? i + e : i2);
+            s1 = g0 ? s0 : (g1 ? v[e] : s1);
+            i1 = g0 ? i0 : (g1 ? i + e : i1);
+            s0 = g0 ? v[e] : s0;
+            i0 = g0 ? i + e : i0;
+        }
+    }
+    u64 k0 = (i0 != 0xFFFFu) ? make_key(__float_as_uint(s0), i0) : 0ull;
+    u64 k1 = (i1 != 0xFFFFu) ? make_key(__float_as_uint(s1), i1) : 0ull;
+    u64 k2 = (i2 != 0xFFFFu) ? make_key(__float_as_uint(s2), i2) : 0ull;
+    win_key = 0;
+    int num = 0;
+    u64 last = 0;
+    for (int r = 0; r < K; r++) {
+        const u64 m = group_max<G>(k0);
+        if (m == 0) break;  // group-uniform
+        num++;
+        last = m;
+        if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }  // unique winner pops its head
+        if ((int)li == r) win_key = m;
+    }
+    // could a dropped entry belong to the answer?  K ranks filled: only if it ties or beats the weakest winner;
+    // fewer than K ranks filled: any dropped entry at all
+    const bool doubt = (num == K) ? (lost >= unord_f32((u32)(last >> 32))) : (lost > -INFINITY);
+    if (((__ballot(doubt) >> (gi * G)) & gmask) != 0)  // group-uniform
+        return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key);
+    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
+    for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
     return num;
 }
 
@@ -377,20 +575,26 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
 template <int G, int BITS, int TM, bool WIDE, int U, int PU>
 __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     constexpr int NG = 64 / G;
+    constexpr int LOG2G = G == 8 ? 3 : (G == 16 ? 4 : (G == 32 ? 5 : 6));
+    typedef typename ItemT<WIDE>::type item_t;
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
     const u32 waves_per_block = blockDim.x >> 6;
     const u32 gi = lane / G, li = lane % G;
+    // per wave: NG score vectors | NG hit lists (list_cap u64 slots each)
     const u32 wave_words = NG * (a.s_stride + 2 * a.list_cap);
     u32 *wbase = lds + wave * wave_words;
     u32 *S = wbase + gi * a.s_stride;
     u64 *list = (u64 *)(wbase + NG * a.s_stride) + gi * a.list_cap;
+    item_t *items = (item_t *)list;
     const u32 nb = a.db.n_branches;
     const u32 k = a.db.k;
     const float T = a.db.T;
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
-    const int cap = (int)a.list_cap - 1;  // one slot is kept for the zero sentinel behind the hits
+    // chunk items the list can take (3U slots of slack for the read-ahead of accumulate_chunks)
+    const int cap_items = (int)(a.list_cap * (sizeof(u64) / sizeof(item_t))) - 3 * U - 2;
+    const int cap_rows = (int)a.list_cap - 1;  // row descriptors (fallback path), one slot for the sentinel
 
     for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
     wave_lds_fence();
@@ -398,6 +602,10 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     const u64 n_tiles = (a.n_reads + NG - 1) / NG;
     const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
     const u64 wave_count = (u64)gridDim.x * waves_per_block;
+#ifdef RK_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_ = rk_now();
+#endif
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         const u64 r = tile * NG + gi;
         const bool have = r < a.n_reads;
@@ -416,76 +624,107 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         const u32 *rec = a.packed + (have ? r : 0ull) * a.words_per_read;  // in-bounds for idle groups too
 
         u32 pos = 0;
-        while (__any(pos < Q)) {
-            // ---- probe: fill the hit list (k-mer order preserved by the rank compaction) ----
-            int cnt = 0;
-            while (true) {
-                const bool more = (pos < Q) && (cnt + PU * G <= cap);
-                if (!__any(more)) break;
-                u64 desc[PU];
+        int cnt = 0;  // chunk items waiting in the list
+        auto flush = [&]() {
+            wave_lds_fence();
+            RK_STAMP(3);
+            if (!(RK_ABLATE & 1)) accumulate_chunks<G, U, WIDE>(S, nb, items, cnt, li, a.db.rows, QT, T);
+            wave_lds_fence();
+            RK_STAMP(4);
+            cnt = 0;
+        };
+        RK_STAMP(0);  // tile setup
+        while (true) {
+            const bool more = pos < Q;
+            if (!__any(more)) break;
+            // ---- probe PU*G positions: every descriptor gather of the batch is in flight together ----
+            u64 desc[PU];
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const u32 j = pos + u * G + li;
+                const bool okj = more && j < Q;
+                if (TM != TM_HASH) {  // branch-free gather: out-of-range lanes re-read position 0 and drop the result later
+                    desc[u] = extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k);
+                } else {
+                    desc[u] = 0;
+                    if (okj) desc[u] = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                }
+            }
+            if (TM != TM_HASH) {
+#pragma unroll
+                for (int u = 0; u < PU; u++) desc[u] = lookup_desc<BITS, TM>(a.db, desc[u]);
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
                     const u32 j = pos + u * G + li;
-                    const bool okj = more && j < Q;
-                    if (TM != TM_HASH) {  // branch-free gather: out-of-range lanes re-read position 0 and drop the result later
-                        desc[u] = extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k);
-                    } else {
-                        desc[u] = 0;
-                        if (okj) desc[u] = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                    desc[u] = (more && j < Q) ? desc[u] : 0ull;
+                }
+            }
+            asm volatile("" ::"v"((u32)desc[0]), "v"((u32)desc[PU - 1]));
+            RK_STAMP(1);  // probe: codes + descriptor gathers (includes their latency)
+            // ---- chunks per row and their exclusive prefix sums in k-mer order (lane order inside a sub-batch) ----
+            u32 nch[PU], excl[PU];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;  // padded row length, 0 = miss
+                nch[u] = (lenp + G - 1) >> LOG2G;
+                u32 incl = nch[u];
+                if (G == 16) {  // a group is one DPP row: row_shr with bound_ctrl shifts zeros in, no LDS crossbar
+                    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);
+                    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+                    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+                    incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+                } else {
+#pragma unroll
+                    for (int sft = 1; sft < G; sft <<= 1) {
+                        const u32 t = __shfl_up(incl, sft, G);
+                        incl += (li >= (u32)sft) ? t : 0u;
                     }
                 }
-                if (TM != TM_HASH) {
-#pragma unroll
-                    for (int u = 0; u < PU; u++) desc[u] = lookup_desc<BITS, TM>(a.db, desc[u]);
+                excl[u] = (u32)total + incl - nch[u];
+                total += (int)__shfl(incl, G - 1, G);
+            }
+            // ---- room in the list? (decisions are per group, actions are taken by the whole wave) ----
+            if (__any(more && cnt + total > cap_items)) flush();
+            if (__any(more && total > cap_items)) {
+                // a batch that does not fit an empty list (very long rows): one descriptor per row and the row cursor,
+                // in parts of at most cap_rows rows
+                const int per_part = cap_rows / G;  // sub-batches per part (>= 1: list_cap > G)
+                for (int u_lo = 0; u_lo < PU; u_lo += per_part) {
+                    int rc = 0;
 #pragma unroll
                     for (int u = 0; u < PU; u++) {
-                        const u32 j = pos + u * G + li;
-                        desc[u] = (more && j < Q) ? desc[u] : 0ull;
+                        const bool part = u >= u_lo && u < u_lo + per_part;
+                        const bool hit = part && ((u32)desc[u] & DESC_LEN_MASK) != 0;
+                        const u64 bal = __ballot(hit);
+                        const u64 sub = (bal >> (gi * G)) & gmask;
+                        if (hit) list[rc + __builtin_popcountll(sub & ((1ull << li) - 1))] = desc[u];
+                        rc += __builtin_popcountll(sub);
                     }
+                    if (li == 0) list[rc] = 0;  // sentinel: an empty row ends the cursor
+                    wave_lds_fence();
+                    if (!(RK_ABLATE & 1) && __any(rc > 0)) accumulate_list<G, U, WIDE>(S, nb, list, rc, li, a.db.rows, QT, T);
+                    wave_lds_fence();
                 }
+            } else {
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
-                    bool hit = ((u32)desc[u] & DESC_LEN_MASK) != 0;
-                    u64 b = __ballot(hit);
-                    u32 sub = (u32)((b >> (gi * G)) & gmask);
-                    if (G == 64) {
-                        u64 below = b & ((1ull << li) - 1);
-                        if (hit) list[cnt + __builtin_popcountll(below)] = desc[u];
-                        cnt += __builtin_popcountll(b);
-                    } else {
-                        if (hit) list[cnt + __builtin_popcount(sub & ((1u << li) - 1))] = desc[u];
-                        cnt += __builtin_popcount(sub);
+                    const u64 off8 = desc[u] >> DESC_LEN_BITS;
+                    const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;
+                    const int base = cnt + (int)excl[u];
+                    for (u32 c = 0; __any(c < nch[u]); c++) {
+                        if (c < nch[u]) {
+                            const u32 left = lenp - c * G;
+                            items[base + (int)c] = make_item<G, WIDE>(off8 + (u64)c * G, left < (u32)G ? left : (u32)G);
+                        }
                     }
                 }
-                if (more) pos += PU * G;
+                cnt += total;
             }
-            if constexpr (PU > 1) {
-                while (true) {  // tail passes, one group-width at a time
-                    const bool more = (pos < Q) && (cnt + G <= cap);
-                    if (!__any(more)) break;
-                    u64 d = 0;
-                    const u32 j = pos + li;
-                    const bool okj = more && j < Q;
-                    if (TM != TM_HASH) {
-                        u64 dd = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k));
-                        d = okj ? dd : 0ull;
-                    } else if (okj) {
-                        d = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
-                    }
-                    bool hit = ((u32)d & DESC_LEN_MASK) != 0;
-                    u64 b = __ballot(hit);
-                    u32 sub = (u32)((b >> (gi * G)) & gmask);
-                    if (hit) list[cnt + __builtin_popcount(sub & ((1u << li) - 1))] = d;
-                    cnt += __builtin_popcount(sub);
-                    if (more) pos += G;
-                }
-            }
-            if (li == 0) list[cnt] = 0;  // sentinel: an empty row ends the cursor
-            wave_lds_fence();
-            // ---- accumulate in k-mer order ----
-            if (!(RK_ABLATE & 1) && __any(cnt > 0)) accumulate_list<G, U, WIDE>(S, nb, list, cnt, li, a.db.rows, QT, T);
-            wave_lds_fence();
+            if (more) pos += PU * G;
+            RK_STAMP(2);  // scans + item emission
         }
+        if (__any(cnt > 0)) flush();
 
         // ---- select + weigh + store (also resets S) ----
         u64 win_key;
@@ -493,9 +732,15 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         if (RK_ABLATE & 2) { win_key = list[0]; for (u32 i = li; i < nb; i += G) S[i] = S_UNTOUCHED; }
         else numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
         wave_lds_fence();
+        RK_STAMP(5);  // select
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
+        RK_STAMP(6);  // weigh + store
     }
+#ifdef RK_STAMPS
+    if (lane == 0 && wave_global < 4096)
+        for (int i = 0; i < 8; i++) rk_stamp_buf[wave_global * 8 + i] = st_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

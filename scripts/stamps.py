@@ -1,0 +1,36 @@
+"""Diagnostic: in-kernel phase shares of place_packed_kernel (s_memtime stamps, -DRK_STAMPS build; never the product)."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = "/tmp/librk_stamps.so"
+extra = sys.argv[1:]
+flags = [a for a in extra if a.startswith("-D")]
+table = next((a.split("=")[1] for a in extra if a.startswith("--table=")), "auto")
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DRK_STAMPS"] + flags +
+               ["-o", so, os.path.join(ROOT, "rappas_amd/csrc/rk_engine.hip")], check=True)
+os.environ["RK_LIB"] = so
+import numpy as np, torch
+import rappas_amd as ra
+from rappas_amd import synth
+sdb = synth.make_config_db("C2")
+mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": ra.RK_TABLE_HASH}[table]
+db = ra.PhyloKmerDB.from_synth(sdb, table_mode=mode)
+pp = ra.PlacementProcess(db)
+n = 4_000_000
+wpr = db.packed_words(150)
+packed = torch.randint(-2**31, 2**31, (n, wpr), dtype=torch.int64, device="cuda").to(torch.int32)
+packed[:, wpr - 1] &= (1 << (300 - 32 * (wpr - 1))) - 1
+pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
+pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
+lib = ra._lib.load()
+nw = 2048
+buf = (C.c_ulonglong * (nw * 8))()
+lib.rk_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.rk_debug_read_stamps(buf, nw) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 8).astype(np.float64)
+tot = a.sum(1)
+names = ["tile setup", "probe (codes+gathers)", "scan+emit items", "pre-accumulate fence", "accumulate", "select", "weigh+store", "-"]
+print(db.kernel_name())
+print("median wave cycles:", np.median(tot), " per tile:", np.median(tot) / (n / 4 / nw))
+for i, nm in enumerate(names[:7]):
+    print(f"  {nm:24s} {100 * np.median(a[:, i] / tot):5.1f} %   {np.median(a[:, i]) / (n / 4 / nw):8.0f} cycles/tile")
