@@ -47,8 +47,8 @@ extern "C" {
 /* k-mer -> row lookup structure */
 #define RK_TABLE_AUTO 0   /* direct when sigma^k slots fit the budget, else hash */
 #define RK_TABLE_HASH 1   /* open-addressed (linear probing), 16-byte slots {key, row descriptor} */
-#define RK_TABLE_DIRECT 2 /* identity-hashed, collision-free special case over all sigma^k codes: compact blocks of
-                             16 k-mers (2 bytes per k-mer, L2-resident); falls back to DIRECT8 if a row exceeds 2040 entries */
+#define RK_TABLE_DIRECT 2 /* identity-hashed, collision-free special case over all sigma^k codes: compact 16-byte blocks of
+                             12 k-mers (1.33 bytes per k-mer, L2-resident); falls back to DIRECT8 if a row exceeds 2040 entries */
 #define RK_TABLE_DIRECT8 4 /* identity-hashed, one 8-byte row descriptor per code */
 
 /* per-read result flags */

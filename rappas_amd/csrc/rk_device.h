@@ -24,13 +24,14 @@ constexpr u32 ROW_UNIT = 8;  // entries per 64-byte line; rows are line-aligned 
 
 // k-mer -> row lookup flavours (template parameter of the kernels)
 constexpr int TM_HASH = 0, TM_DIRECT8 = 1, TM_COMPACT = 2;
+constexpr u32 COMPACT_KMERS = 12;  // k-mers per 16-byte block of the compact direct table
 
 // Untouched marker for the per-read LDS score vector (a NaN pattern no finite sum can produce).
 constexpr u32 S_UNTOUCHED = 0xFFFFFFFFu;
 
 struct DbView {
     const u64 *direct;   // [sigma^k] row descriptors (RK_TABLE_DIRECT8) or nullptr
-    const uint4 *compact;  // [ceil(sigma^k/16)][2] blocks {u64 first unit, u64 pad | 16 x u8 units} (RK_TABLE_DIRECT) or nullptr
+    const uint4 *compact;  // [ceil(sigma^k/12)] blocks {u32 first unit, 12 x u8 units} (RK_TABLE_DIRECT) or nullptr
     const uint4 *slots;  // [hash_mask+1] {key+1 lo, key+1 hi, desc lo, desc hi} (RK_TABLE_HASH) or nullptr
     u64 hash_mask;
     const unsigned char *rows;

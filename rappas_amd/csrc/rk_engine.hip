@@ -261,26 +261,28 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     }
 
     // ---- table ----
-    // DIRECT  : compact blocks, 32 bytes per 16 consecutive k-mers {u64 first row unit, 16 x u8 units per row}: 2 bytes
-    //           per k-mer, small enough to live in the XCD L2s; a row's offset is the block base plus a byte prefix sum.
-    //           Needs rows of <= 255 units (2040 entries); otherwise DIRECT falls back to DIRECT8.
+    // DIRECT  : compact blocks, 16 bytes per 12 consecutive k-mers {u32 first row unit, 12 x u8 units per row}: 1.33 bytes
+    //           per k-mer (1.4 MiB at k=10), small enough to live in the XCD L2s, one dwordx4 gather per probe; a row's
+    //           offset is the block base plus a byte prefix sum.  Needs rows of <= 255 units (2040 entries) and a blob
+    //           of < 2^32 units (256 GiB); otherwise DIRECT falls back to DIRECT8.
     // DIRECT8 : one 8-byte descriptor per k-mer.
     // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
-    if (mode == RK_TABLE_DIRECT && max_units > 255) mode = RK_TABLE_DIRECT8;
+    if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32))) mode = RK_TABLE_DIRECT8;
     std::vector<uint64_t> table;
     uint64_t slots = 0, hash_mask = 0;
     try {
         if (mode == RK_TABLE_DIRECT) {
             slots = space;
-            const uint64_t n_blocks = (space + 15) / 16;
-            table.assign(n_blocks * 4, 0);
+            const uint64_t n_blocks = (space + COMPACT_KMERS - 1) / COMPACT_KMERS;
+            table.assign(n_blocks * 2, 0);
             unsigned char *tb = (unsigned char *)table.data();
             uint64_t next_unit = 1, ki = 0;
             for (uint64_t blk = 0; blk < n_blocks; blk++) {
-                memcpy(tb + blk * 32, &next_unit, 8);
-                while (ki < n_keys && (order[ki].first >> 4) == blk) {
+                const uint32_t base32 = (uint32_t)next_unit;
+                memcpy(tb + blk * 16, &base32, 4);
+                while (ki < n_keys && order[ki].first / COMPACT_KMERS == blk) {
                     const uint64_t units = ((uint32_t)desc[order[ki].second] & DESC_LEN_MASK) / ROW_UNIT;
-                    tb[blk * 32 + 16 + (order[ki].first & 15)] = (unsigned char)units;
+                    tb[blk * 16 + 4 + (order[ki].first % COMPACT_KMERS)] = (unsigned char)units;
                     next_unit += units;
                     ki++;
                 }

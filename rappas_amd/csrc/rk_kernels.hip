@@ -116,29 +116,54 @@ __device__ __forceinline__ u64 dense_index(u64 code, u32 k) {
     return idx;
 }
 
+// Table lookups are split into a FETCH (one unconditional gather per k-mer, so that a whole batch of them can be
+// in flight) and a branch-free DECODE.  (Written as one function, hipcc sank part of the 16-byte load under a
+// data-dependent branch and waited vmcnt(0) after every probe: the batch ran one gather at a time.)
+struct RawSlot {
+    uint4 v;
+};
+
 template <int BITS, int TM>
-__device__ __forceinline__ u64 lookup_desc(const DbView &db, u64 code) {
+__device__ __forceinline__ RawSlot lookup_fetch(const DbView &db, u64 code) {
+    RawSlot r;
     if (TM == TM_COMPACT) {
-        // block of 16 consecutive k-mers: {u64 first 64-byte unit of the block's rows, u64 unused, 16 x u8 units per row}
         const u64 idx = dense_index<BITS>(code, db.k);
-        const u32 i = (u32)idx & 15;
-        const uint4 *blk = db.compact + (idx >> 4) * 2;
-        const uint4 h = blk[0];
-        const uint4 n = blk[1];
-        // byte prefix sum of the 16 per-row unit counts: running sums over whole words (v_sad_u8 accumulates),
-        // then the partial word of k-mer i
-        const u32 c0 = __builtin_amdgcn_sad_u8(n.x, 0u, 0u);
-        const u32 c1 = __builtin_amdgcn_sad_u8(n.y, 0u, c0);
-        const u32 c2 = __builtin_amdgcn_sad_u8(n.z, 0u, c1);
+        r.v = db.compact[(u32)(idx / COMPACT_KMERS)];
+    } else {  // TM_DIRECT8
+        const uint2 d = *(const uint2 *)(db.direct + dense_index<BITS>(code, db.k));
+        r.v = make_uint4(d.x, d.y, 0u, 0u);
+    }
+    return r;
+}
+
+template <int BITS, int TM>
+__device__ __forceinline__ u64 lookup_decode(const DbView &db, const RawSlot &r, u64 code) {
+    if (TM == TM_COMPACT) {
+        // 16-byte block of COMPACT_KMERS (12) consecutive k-mers: {u32 first 64-byte unit of the block's rows,
+        // 12 x u8 units per row}; the row offset is the block base plus a byte prefix sum (v_sad_u8 accumulates)
+        const u64 idx = dense_index<BITS>(code, db.k);
+        const u32 i = (u32)(idx % COMPACT_KMERS);
+        const uint4 n = r.v;
+        const u32 c0 = __builtin_amdgcn_sad_u8(n.y, 0u, 0u);
+        const u32 c1 = __builtin_amdgcn_sad_u8(n.z, 0u, c0);
         const u32 word = i >> 2, sh = (i & 3u) * 8u;
-        const u32 wsel = word == 0 ? n.x : (word == 1 ? n.y : (word == 2 ? n.z : n.w));
-        const u32 csel = word == 0 ? 0u : (word == 1 ? c0 : (word == 2 ? c1 : c2));
+        const u32 wsel = word == 0 ? n.y : (word == 1 ? n.z : n.w);
+        const u32 csel = word == 0 ? 0u : (word == 1 ? c0 : c1);
         const u32 prefix = __builtin_amdgcn_sad_u8(wsel & ((1u << sh) - 1u), 0u, csel);
         const u32 mine = (wsel >> sh) & 0xFFu;
-        const u64 unit = (((u64)h.y << 32) | h.x) + prefix;
-        return mine ? (((unit * ROW_UNIT) << DESC_LEN_BITS) | (u64)(mine * ROW_UNIT)) : 0ull;
-    } else if (TM == TM_DIRECT8) {
-        return db.direct[dense_index<BITS>(code, db.k)];
+        const u64 unit = (u64)n.x + prefix;
+        const u64 d = ((unit * ROW_UNIT) << DESC_LEN_BITS) | (u64)(mine * ROW_UNIT);
+        return d & (0ull - (u64)(mine != 0));
+    } else {
+        return ((u64)r.v.y << 32) | r.v.x;
+    }
+}
+
+template <int BITS, int TM>
+__device__ __forceinline__ u64 lookup_desc(const DbView &db, u64 code) {
+    if (TM != TM_HASH) {
+        const RawSlot r = lookup_fetch<BITS, TM>(db, code);
+        return lookup_decode<BITS, TM>(db, r, code);
     } else {
         u64 h = mix64(code) & db.hash_mask;
         const u64 want = code + 1;
@@ -622,6 +647,12 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         const u32 Q = (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
         const float QT = (float)(int)Q * T;  // int * float (PlacementProcess.java:728)
         const u32 *rec = a.packed + (have ? r : 0ull) * a.words_per_read;  // in-bounds for idle groups too
+        // warm the cache with the NEXT tile's packed records (streamed from HBM, ~2 us if met cold by the probe)
+        u32 warm = 0;
+        {
+            const u64 rn = (tile + wave_count) * NG + gi;
+            if (rn < a.n_reads) warm = a.packed[rn * a.words_per_read + (li < a.words_per_read ? li : 0u)];
+        }
 
         u32 pos = 0;
         int cnt = 0;  // chunk items waiting in the list
@@ -651,12 +682,15 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                 }
             }
             if (TM != TM_HASH) {
+                RawSlot raw[PU];
 #pragma unroll
-                for (int u = 0; u < PU; u++) desc[u] = lookup_desc<BITS, TM>(a.db, desc[u]);
+                for (int u = 0; u < PU; u++) raw[u] = lookup_fetch<BITS, TM>(a.db, desc[u]);
+                __builtin_amdgcn_sched_barrier(0);  // all PU gathers are issued before any of them is decoded
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
                     const u32 j = pos + u * G + li;
-                    desc[u] = (more && j < Q) ? desc[u] : 0ull;
+                    const u64 d = lookup_decode<BITS, TM>(a.db, raw[u], desc[u]);
+                    desc[u] = (more && j < Q) ? d : 0ull;
                 }
             }
             asm volatile("" ::"v"((u32)desc[0]), "v"((u32)desc[PU - 1]));
@@ -735,6 +769,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         RK_STAMP(5);  // select
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
+        asm volatile("" ::"v"(warm));  // keep the warming load alive
         RK_STAMP(6);  // weigh + store
     }
 #ifdef RK_STAMPS
