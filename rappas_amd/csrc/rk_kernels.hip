@@ -562,11 +562,11 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
         // :441-448  sum_{ascending} pow(10, (double)(float)(score - shift));  (:418 sums in heap order when
         // shift == 0 -- same terms, order differs only in the last ulp of a double)
         float d32 = score - shift;
-        double term = mine ? pow(10.0, (double)d32) : 0.0;
+        double term = mine ? exp10((double)d32) : 0.0;
         double sum = 0.0;
         for (int q = numBest - 1; q >= 0; q--) sum += shfl_f64(term, q, G);
         float shift2 = (-308.0f >= lowest) ? best : 0.0f;  // :978-980 uses the true minimum
-        double ratio = mine ? pow(10.0, (double)score - (double)shift2) / sum : 0.0;  // :392-394
+        double ratio = mine ? exp10((double)score - (double)shift2) / sum : 0.0;  // :392-394 (Math.pow(10.0, x))
         double best_ratio = shfl_f64(ratio, 0, G);
         bool fail = mine && li > 0 && (ratio < best_ratio * (double)a.keep_factor);  // :998-1000
         u64 fb = __ballot(fail);
@@ -746,7 +746,10 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     const u64 off8 = desc[u] >> DESC_LEN_BITS;
                     const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;
                     const int base = cnt + (int)excl[u];
-                    for (u32 c = 0; __any(c < nch[u]); c++) {
+                    // most rows are 1-2 chunks: those are written without a wave vote, the rest in a voted loop
+                    if (nch[u] > 0) items[base] = make_item<G, WIDE>(off8, lenp < (u32)G ? lenp : (u32)G);
+                    if (nch[u] > 1) items[base + 1] = make_item<G, WIDE>(off8 + G, lenp - G < (u32)G ? lenp - G : (u32)G);
+                    for (u32 c = 2; __any(c < nch[u]); c++) {
                         if (c < nch[u]) {
                             const u32 left = lenp - c * G;
                             items[base + (int)c] = make_item<G, WIDE>(off8 + (u64)c * G, left < (u32)G ? left : (u32)G);
