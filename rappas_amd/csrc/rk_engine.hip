@@ -417,6 +417,10 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         cap = (uint32_t)(c > 256 ? 256 : c);
         if (cap < min_cap) cap = min_cap;
     }
+    if (const char *e = getenv("RK_LIST_CAP")) {  // developer knob: trade hit-list room for occupancy
+        uint32_t v = (uint32_t)atoi(e);
+        if (v >= min_cap && v <= 4096) cap = v;
+    }
     cap &= ~1u;  // keeps every group's score vector 16-byte aligned
     g.G = G; g.NG = NG; g.s_stride = s_stride; g.list_cap = cap; g.pu = pu;
     g.lds_per_wave = bytes_for(G, cap);
