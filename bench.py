@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--db-scale", type=float, default=1.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse the multi-rank path on one GPU")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
     return ap.parse_args()
 
 
@@ -105,11 +107,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the placement engine has no CPU fallback")
+    if a.force_device >= 0:
+        local_rank = a.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world
 
     import rappas_amd as ra
@@ -196,7 +203,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
