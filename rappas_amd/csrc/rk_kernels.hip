@@ -671,15 +671,9 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
             // ---- probe PU*G positions: every descriptor gather of the batch is in flight together ----
             u64 desc[PU];
 #pragma unroll
-            for (int u = 0; u < PU; u++) {
+            for (int u = 0; u < PU; u++) {  // out-of-range lanes re-read position 0 and drop the result later
                 const u32 j = pos + u * G + li;
-                const bool okj = more && j < Q;
-                if (TM != TM_HASH) {  // branch-free gather: out-of-range lanes re-read position 0 and drop the result later
-                    desc[u] = extract_code<BITS>(rec, a.words_per_read, okj ? j : 0u, k);
-                } else {
-                    desc[u] = 0;
-                    if (okj) desc[u] = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
-                }
+                desc[u] = extract_code<BITS>(rec, a.words_per_read, (more && j < Q) ? j : 0u, k);
             }
             if (TM != TM_HASH) {
                 RawSlot raw[PU];
@@ -691,6 +685,35 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     const u32 j = pos + u * G + li;
                     const u64 d = lookup_decode<BITS, TM>(a.db, raw[u], desc[u]);
                     desc[u] = (more && j < Q) ? d : 0ull;
+                }
+            } else {
+                // open addressing: the home slots of the whole batch are gathered together (at load <= 0.5 most
+                // probes end there); lanes whose slot holds another key walk on, the wave loops until all are done
+                uint4 slot[PU];
+                u64 h[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    h[u] = mix64(desc[u]) & a.db.hash_mask;
+                    slot[u] = a.db.slots[h[u]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const u32 j = pos + u * G + li;
+                    const u64 want = desc[u] + 1;
+                    u64 key = ((u64)slot[u].y << 32) | slot[u].x;
+                    u64 d = ((u64)slot[u].w << 32) | slot[u].z;
+                    bool walking = (more && j < Q) && key != want && key != 0;
+                    while (__any(walking)) {
+                        if (walking) {
+                            h[u] = (h[u] + 1) & a.db.hash_mask;
+                            const uint4 s2 = a.db.slots[h[u]];
+                            key = ((u64)s2.y << 32) | s2.x;
+                            d = ((u64)s2.w << 32) | s2.z;
+                            walking = key != want && key != 0;
+                        }
+                    }
+                    desc[u] = ((more && j < Q) && key == want) ? d : 0ull;
                 }
             }
             asm volatile("" ::"v"((u32)desc[0]), "v"((u32)desc[PU - 1]));
