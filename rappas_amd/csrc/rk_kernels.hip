@@ -497,24 +497,39 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K
     const u32 n4 = (nb + 3) / 4;
     float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
     u32 i0 = 0xFFFFu, i1 = 0xFFFFu, i2 = 0xFFFFu;
-    for (u32 q = li; q < n4; q += G) {
-        const uint4 v4 = S4[q];
-        const u32 i = 4 * q;
-        const float v[4] = {__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w)};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const bool in = i + e < nb;
-            // strict '>' keeps the smaller branch id ahead among equal scores; NaN (untouched) compares false
-            const bool g0 = in && v[e] > s0, g1 = in && v[e] > s1, g2 = in && v[e] > s2;
-            const float drop = g2 ? s2 : (in ? v[e] : -INFINITY);
-            lost = fmaxf(lost, drop);  // fmaxf ignores the NaN marker
-            s2 = g1 ? s1 : (g2 ? v[e] : s2);
-            i2 = g1 ? i1 : (g2 ? i + e : i2);
-            s1 = g0 ? s0 : (g1 ? v[e] : s1);
-            i1 = g0 ? i0 : (g1 ? i + e : i1);
-            s0 = g0 ? v[e] : s0;
-            i0 = g0 ? i + e : i0;
+    // sorted insertion into the lane's top three; strict '>' keeps the smaller branch id ahead among equal scores and
+    // is false for the NaN marker of untouched branches
+    auto feed = [&](float v, u32 idx, bool in) {
+        const bool g0 = in && v > s0, g1 = in && v > s1, g2 = in && v > s2;
+        const float drop = g2 ? s2 : (in ? v : -INFINITY);
+        lost = fmaxf(lost, drop);  // fmaxf ignores the NaN marker
+        s2 = g1 ? s1 : (g2 ? v : s2);
+        i2 = g1 ? i1 : (g2 ? idx : i2);
+        s1 = g0 ? s0 : (g1 ? v : s1);
+        i1 = g0 ? i0 : (g1 ? idx : i1);
+        s0 = g0 ? v : s0;
+        i0 = g0 ? idx : i0;
+    };
+    const u32 n4_full = nb / 4;  // quads that lie entirely below nb need no bounds test
+    if (li < n4_full) {
+        uint4 cur = S4[li];
+        for (u32 q = li; q < n4_full; q += G) {
+            const uint4 v4 = cur;
+            if (q + G < n4_full) cur = S4[q + G];  // next quad is in flight while this one is ranked
+            const u32 i = 4 * q;
+            feed(__uint_as_float(v4.x), i, true);
+            feed(__uint_as_float(v4.y), i + 1, true);
+            feed(__uint_as_float(v4.z), i + 2, true);
+            feed(__uint_as_float(v4.w), i + 3, true);
         }
+    }
+    if ((nb & 3u) && (n4_full % G) == li) {  // the partial last quad
+        const uint4 v4 = S4[n4_full];
+        const u32 i = 4 * n4_full;
+        feed(__uint_as_float(v4.x), i, i < nb);
+        feed(__uint_as_float(v4.y), i + 1, i + 1 < nb);
+        feed(__uint_as_float(v4.z), i + 2, i + 2 < nb);
+        feed(__uint_as_float(v4.w), i + 3, i + 3 < nb);
     }
     u64 k0 = (i0 != 0xFFFFu) ? make_key(__float_as_uint(s0), i0) : 0ull;
     u64 k1 = (i1 != 0xFFFFu) ? make_key(__float_as_uint(s1), i1) : 0ull;
