@@ -15,6 +15,9 @@
 
 using namespace rk;
 
+#ifndef RK_WG_MIN_BRANCHES
+#define RK_WG_MIN_BRANCHES 8192u  // above this a single-wave score vector leaves <= 4 waves per CU: use place_wg_kernel
+#endif
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
 #endif
@@ -114,6 +117,7 @@ struct rk_db {
     unsigned char *d_alpha = nullptr;  // table[256] | alts[320] | alt_count[16]
     uint32_t lanes_per_read = 0;       // 0 = auto
     uint32_t waves_per_block = 1;
+    bool indexed = false;              // rows carry an index line (large trees, place_wg_kernel)
     int cu_count = 256;
     size_t lds_per_cu = 160 * 1024;
     hipStream_t stream = nullptr;      // host-path stream
@@ -220,6 +224,12 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
 
     // ---- row blob: every row starts on a 64-byte line and is padded to whole lines (8 entries) with "skip"
     //      entries, so a row of n entries costs exactly ceil(n/8) line requests; line 0 is reserved (all skip) ----
+    // Large trees (n_branches > RK_WG_MIN_BRANCHES): the score vector of one read fills most of a CU's LDS, so a whole
+    // workgroup shares it and every wave owns a branch range (place_wg_kernel).  Rows are then sorted by branch id
+    // and preceded by one 64-byte INDEX line: u16 split[i-1] = number of entries with branch < floor(i * n_branches / 32),
+    // i = 1..32, so a wave finds its slice of a row with two 2-byte loads.  Descriptors still point at the first
+    // entry line; the other kernels never look at the index line.
+    const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES;
     std::vector<uint64_t> desc(n_keys);  // by key number
     uint64_t blob_units = 1;             // 64-byte units
     uint32_t max_len = 0;
@@ -235,6 +245,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
         if (len > max_len) max_len = (uint32_t)len;
         const uint64_t units = (len + ROW_UNIT - 1) / ROW_UNIT;
         if (units > max_units) max_units = units;
+        if (indexed) blob_units += 1;  // the index line
         desc[r] = ((blob_units * 8) << DESC_LEN_BITS) | (units * ROW_UNIT);
         blob_units += units;
     }
@@ -257,6 +268,16 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
                 ep[i].branch = x;
                 ep[i].score = v;
             }
+            if (indexed) {
+                std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
+                uint16_t *split = (uint16_t *)(ep - ROW_UNIT);  // the 64-byte line in front of the row
+                uint64_t e = 0;
+                for (uint32_t i = 1; i <= 32; i++) {
+                    const uint32_t bound = (uint32_t)(((uint64_t)i * d->n_branches) / 32);
+                    while (e < len && ep[e].branch < bound) e++;
+                    split[i - 1] = (uint16_t)e;
+                }
+            }
         }
     }
 
@@ -267,7 +288,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     //           of < 2^32 units (256 GiB); otherwise DIRECT falls back to DIRECT8.
     // DIRECT8 : one 8-byte descriptor per k-mer.
     // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
-    if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32))) mode = RK_TABLE_DIRECT8;
+    if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32) || indexed)) mode = RK_TABLE_DIRECT8;
     std::vector<uint64_t> table;
     uint64_t slots = 0, hash_mask = 0;
     try {
@@ -344,6 +365,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
 #undef DB_TRY
 
     db->convert_uo = d->convert_uo;
+    db->indexed = indexed;
     db->info.alphabet = d->alphabet; db->info.k = d->k; db->info.n_branches = d->n_branches;
     db->info.table_mode = mode; db->info.thr_log10 = d->thr_log10; db->info.thr = d->thr;
     db->info.n_keys = n_keys; db->info.n_entries = n_entries; db->info.table_slots = slots;
@@ -480,6 +502,59 @@ static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, 
     }
 }
 
+// ---- large trees: one workgroup per read ----
+struct WgGeometry {
+    uint32_t nw, s_stride, list_cap, wgs_per_cu;
+    size_t lds;
+};
+
+static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
+    const uint32_t nb = db->info.n_branches;
+    g.s_stride = (nb + 4) & ~3u;
+    const size_t s_bytes = (size_t)g.s_stride * 4;
+    const size_t extra = 256;  // per-wave counters
+    // two workgroups of 8 waves per CU when two score vectors fit, else one workgroup of 16 waves
+    for (uint32_t wgs : {2u, 1u}) {
+        const size_t budget = db->lds_per_cu / wgs;
+        const uint32_t nw_try = wgs == 2 ? 8 : 16;
+        if (budget < s_bytes + extra + (size_t)(nw_try * 16 + 16 + 2) * 8) continue;  // level-2 select scratch must fit the list
+        size_t cap = (budget - s_bytes - extra) / 8;
+        if (cap > 512) cap = 512;
+        g.list_cap = (uint32_t)cap & ~1u;
+        g.wgs_per_cu = wgs;
+        g.nw = wgs == 2 ? 8 : 16;
+        g.lds = s_bytes + (size_t)g.list_cap * 8 + extra;
+        return RK_OK;
+    }
+    return fail(RK_ERR_UNSUPPORTED, "n_branches=%u: the score vector does not fit one CU's LDS (%zu B)", nb, db->lds_per_cu);
+}
+
+template <int BITS, int TM>
+static int launch_wg_v(const rk_db *db, const WgGeometry &g, PlaceArgs a, hipStream_t stream) {
+    a.s_stride = g.s_stride;
+    a.list_cap = g.list_cap;
+    uint64_t blocks = (uint64_t)db->cu_count * g.wgs_per_cu;
+    if (blocks > a.n_reads) blocks = a.n_reads;
+    if (!blocks) return RK_OK;
+    if (db->info.rows_bytes < (1ull << 32)) {
+        auto kern = place_wg_kernel<BITS, TM, false, RK_RING>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * g.nw), g.lds, stream, a);
+    } else {
+        auto kern = place_wg_kernel<BITS, TM, true, RK_RING>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * g.nw), g.lds, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return RK_OK;
+}
+
+static int launch_wg(const rk_db *db, const WgGeometry &g, const PlaceArgs &a, hipStream_t s) {
+    const bool dna = db->info.bits_per_symbol == 2;
+    if (db->info.table_mode == RK_TABLE_HASH) return dna ? launch_wg_v<2, TM_HASH>(db, g, a, s) : launch_wg_v<5, TM_HASH>(db, g, a, s);
+    return dna ? launch_wg_v<2, TM_DIRECT8>(db, g, a, s) : launch_wg_v<5, TM_DIRECT8>(db, g, a, s);
+}
+
 template <int BITS, int TM>
 static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hipStream_t stream) {
     // LDS: S[s_stride] + candidate list + Samb/Camb windows of `chunk` branches (several passes if the tree is large)
@@ -493,6 +568,7 @@ static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hip
         chunk = avail / 8;
         if (chunk > args.s_stride) chunk = args.s_stride;
     }
+    if (chunk == 0 || args.s_stride == 0) return fail(RK_ERR_INVALID, "internal: ambiguity kernel launched without a score-vector geometry");
     m.amb_chunk = (uint32_t)chunk;
     const size_t lds = fixed + 8 * chunk;
     const uint64_t groups = (args.n_reads + 63) / 64;
@@ -529,8 +605,17 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     if (!db) return "";
     Geometry g;
     rk_db *m = const_cast<rk_db *>(db);
+    char buf[200];
+    if (db->indexed && db->lanes_per_read == 0) {
+        WgGeometry wg;
+        if (choose_wg_geometry(db, wg) != RK_OK) return "";
+        snprintf(buf, sizeof(buf), "place_wg_kernel<BITS=%u,%s,%s,U=%d> waves/WG=%u lds/WG=%zuB rows/batch=%u WGs/CU=%u",
+                 db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_HASH ? "HASH" : "DIRECT8",
+                 db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", RK_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu);
+        m->kernel_name = buf;
+        return m->kernel_name.c_str();
+    }
     if (choose_geometry(db, 7, g) != RK_OK) return "";
-    char buf[160];
     snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
              g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
              db->info.rows_bytes < (1ull << 32) ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
@@ -577,8 +662,10 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
         return fail(RK_ERR_INVALID, "rk_place_packed_device: null result array");
     if (!d_lens && (uint64_t)fixed_len * db->info.bits_per_symbol > (uint64_t)words_per_read * 32)
         return fail(RK_ERR_INVALID, "rk_place_packed_device: fixed_len=%u does not fit %u words", fixed_len, words_per_read);
-    Geometry g;
-    rc = choose_geometry(db, p->keep_at_most, g);
+    const bool use_wg = db->indexed && db->lanes_per_read == 0;  // an explicit lanes_per_read forces the single-wave kernel
+    Geometry g{};
+    WgGeometry wg{};
+    rc = use_wg ? choose_wg_geometry(db, wg) : choose_geometry(db, p->keep_at_most, g);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(db->info.device));
     hipStream_t s = (hipStream_t)stream;
@@ -591,8 +678,9 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
     a.has_ascii = ascii ? 1u : 0u;
     a.keep_at_most = p->keep_at_most; a.keep_factor = p->keep_factor; a.ns_bound = p->ns_bound;
     a.o_nrows = d_out->n_rows; a.o_branch = d_out->branch; a.o_score = d_out->score; a.o_lwr = d_out->lwr; a.o_flags = d_out->flags;
-    a.s_stride = g.s_stride; a.list_cap = g.list_cap;
-    rc = launch_place(db, g, a, s);
+    a.s_stride = use_wg ? wg.s_stride : g.s_stride;
+    a.list_cap = use_wg ? wg.list_cap : g.list_cap;
+    rc = use_wg ? launch_wg(db, wg, a, s) : launch_place(db, g, a, s);
     if (rc) return rc;
     if (ascii) {
         AmbArgs m{};

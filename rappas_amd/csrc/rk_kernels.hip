@@ -820,6 +820,241 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// large trees: one WORKGROUP per read (place_wg_kernel)
+//
+// When S[n_branches] takes most of a CU's LDS (C5: 19 999 branches = 80 KB) a single wave per read leaves 2 waves
+// per CU.  Here the NW waves of a workgroup share one score vector and every wave owns a contiguous BRANCH range:
+// rows are stored sorted by branch with a 64-byte index line in front (u16 split[i-1] = entries with branch <
+// floor(i*n_branches/32)), so a wave finds its slice of a row with two 2-byte loads and streams it 64 entries per
+// step.  A branch belongs to exactly one wave and that wave walks the rows in k-mer order, so per-branch float32
+// order is the reference's, with no barrier inside the accumulate phase.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_SLOTS = 4;  // rows per lane in the slice table of a wave: a probe batch holds <= 64 * WG_SLOTS rows
+
+template <bool WIDE, int U>
+__device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list, int cnt, u32 lane, u32 q_lo, u32 q_hi,
+                                                const unsigned char *rows, float QT, float T) {
+    typedef typename OffsetT<WIDE>::type off_t;
+    // ---- phase A: this wave's slice [start, start + n) of every row of the batch (row h lives in lane h%64, slot h/64)
+    off_t start[WG_SLOTS];
+    u32 nn[WG_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < WG_SLOTS; sl++) {
+        const int h = (int)lane + 64 * sl;
+        const bool have = h < cnt;
+        const u64 d = list[have ? h : 0];
+        const off_t off = (off_t)(d >> DESC_LEN_BITS) << 3;  // byte offset of the first entry line
+        const unsigned short *split = (const unsigned short *)(rows + off - 64);
+        const u32 lo_raw = split[q_lo ? q_lo - 1 : 0];
+        const u32 hi = split[q_hi - 1];
+        const u32 lo = q_lo ? lo_raw : 0u;
+        nn[sl] = have ? hi - lo : 0u;
+        start[sl] = off + (off_t)lo * 8;
+    }
+    u64 mk[WG_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < WG_SLOTS; sl++) mk[sl] = __ballot(nn[sl] > 0);
+    // ---- phase B: stream the non-empty slices in row order through the register ring (all state wave-uniform) ----
+    int sl = 0;
+    u64 m = mk[0];
+    int rem = 0;
+    off_t cur = 0;
+    bool done = false;
+    const u32 lane8 = lane * 8;
+    u32 br[U];
+    float sc[U];
+    auto gen = [&](u32 &b, float &v) {
+        if (rem <= 0 && !done) {  // uniform: next non-empty slice
+            while (m == 0 && sl < WG_SLOTS - 1) {
+                sl++;
+                m = sl == 1 ? mk[1] : (sl == 2 ? mk[2] : mk[3]);
+            }
+            if (m != 0) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const off_t st = sl == 0 ? start[0] : (sl == 1 ? start[1] : (sl == 2 ? start[2] : start[3]));
+                const u32 n_ = sl == 0 ? nn[0] : (sl == 1 ? nn[1] : (sl == 2 ? nn[2] : nn[3]));
+                if (WIDE) {
+                    const u32 lo32 = (u32)__builtin_amdgcn_readlane((int)(u32)st, l);
+                    const u32 hi32 = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)st >> 32), l);
+                    cur = (off_t)(((u64)hi32 << 32) | lo32);
+                } else {
+                    cur = (off_t)(u32)__builtin_amdgcn_readlane((int)(u32)st, l);
+                }
+                rem = __builtin_amdgcn_readlane((int)n_, l);
+            } else {
+                done = true;
+            }
+        }
+        const bool ok = (int)lane < rem;
+        const off_t eo = ok ? (off_t)(cur + lane8) : (off_t)0;
+        const uint2 e = *(const uint2 *)(rows + eo);
+        b = e.x;
+        v = __uint_as_float(e.y);
+        rem -= 64;
+        cur += 512;
+    };
+#pragma unroll
+    for (int u = 0; u < U; u++) gen(br[u], sc[u]);
+    while (true) {
+        const bool was_done = done;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            apply_entry(S, nb, br[u], sc[u], QT, T);
+            gen(br[u], sc[u]);
+        }
+        if (was_done) break;  // everything issued since `done` was a skip and everything before it has been applied
+    }
+}
+
+// exact top-K of the quads [q0, q1) of S by K rounds of "largest key below the previous winner" (rare fallback)
+__device__ __forceinline__ int select_rounds64(const u32 *S, u32 nb, u32 q0, u32 q1, u32 lane, int K, u64 &win_key) {
+    const uint4 *S4 = (const uint4 *)S;
+    u64 prev = ~0ull;
+    int num = 0;
+    win_key = 0;
+    for (int r = 0; r < K; r++) {
+        u64 best = 0;
+        for (u32 q = q0 + lane; q < q1; q += 64) {
+            const uint4 v4 = S4[q];
+            const u32 raw[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const u32 i = 4 * q + e;
+                const u64 key = (raw[e] != S_UNTOUCHED && i < nb) ? make_key(raw[e], i) : 0ull;
+                best = (key < prev && key > best) ? key : best;
+            }
+        }
+        const u64 mx = group_max<64>(best);
+        if (mx == 0) break;
+        if ((int)lane == r) win_key = mx;
+        prev = mx;
+        num++;
+    }
+    return num;
+}
+
+template <int BITS, int TM, bool WIDE, int U>
+__global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
+    extern __shared__ u32 lds[];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    u32 *S = lds;
+    u64 *list = (u64 *)(lds + a.s_stride);
+    u32 *wcnt = (u32 *)(list + a.list_cap);  // [NW] hits per wave of the current probe batch
+    const u32 nb = a.db.n_branches, k = a.db.k;
+    const float T = a.db.T;
+    const int K = (int)a.keep_at_most;
+    u32 batch = blockDim.x;  // k-mer positions probed per round: every hit must fit the list / the slice table
+    if (batch > a.list_cap - 1) batch = a.list_cap - 1;
+    if (batch > 64 * WG_SLOTS) batch = 64 * WG_SLOTS;
+    const u32 q_lo = wave * 32 / NW, q_hi = (wave + 1) * 32 / NW;  // branch range of this wave (index-line boundaries)
+    const u32 n4 = (nb + 3) / 4, n4_full = nb / 4;
+    const u32 qpw = (n4 + NW - 1) / NW;                             // quads of S this wave scans in the select phase
+    const u32 sq0 = wave * qpw < n4 ? wave * qpw : n4;
+    const u32 sq1 = sq0 + qpw < n4 ? sq0 + qpw : n4;
+    uint4 *S4w = (uint4 *)S;
+    const uint4 *S4 = (const uint4 *)S;
+    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
+    for (u32 i = tid; i < a.s_stride; i += blockDim.x) S[i] = S_UNTOUCHED;
+    __syncthreads();
+
+    for (u64 r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        const u32 R = a.lens ? a.lens[r] : a.fixed_len;
+        const u32 fin = a.flags_in ? a.flags_in[r] : 0u;
+        u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        if (R < k) flags |= RK_FLAG_TOO_SHORT;
+        const u32 Q = (!is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
+        const float QT = (float)(int)Q * T;
+        const u32 *rec = a.packed + r * a.words_per_read;
+
+        for (u32 pos0 = 0; pos0 < Q; pos0 += batch) {
+            // ---- probe: thread <-> k-mer position; hits compacted in position order across the workgroup ----
+            const u32 j = pos0 + tid;
+            const bool ok = tid < batch && j < Q;
+            u64 desc = 0;
+            if (TM != TM_HASH) {
+                const u64 d = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, ok ? j : 0u, k));
+                desc = ok ? d : 0ull;
+            } else if (ok) {
+                desc = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+            }
+            const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
+            const u64 bal = __ballot(hit);
+            if (lane == 0) wcnt[wave] = (u32)__builtin_popcountll(bal);
+            __syncthreads();
+            u32 base = 0, cnt = 0;
+            for (u32 w = 0; w < NW; w++) {
+                const u32 c = wcnt[w];
+                base += w < wave ? c : 0u;
+                cnt += c;
+            }
+            if (hit) list[base + __builtin_popcountll(bal & ((1ull << lane) - 1))] = desc;
+            __syncthreads();
+            // ---- accumulate: every wave applies its branch range of every row, rows in k-mer order ----
+            if (cnt > 0) wave_accumulate<WIDE, U>(S, nb, list, (int)cnt, lane, q_lo, q_hi, a.db.rows, QT, T);
+            __syncthreads();
+        }
+
+        // ---- select, level 1: every wave ranks its segment of S (three best per lane, K rounds of wave max) ----
+        float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
+        u32 i0 = 0xFFFFu, i1 = 0xFFFFu, i2 = 0xFFFFu;
+        auto feed = [&](float v, u32 idx, bool in) {
+            const bool g0 = in && v > s0, g1 = in && v > s1, g2 = in && v > s2;
+            const float drop = g2 ? s2 : (in ? v : -INFINITY);
+            lost = fmaxf(lost, drop);
+            s2 = g1 ? s1 : (g2 ? v : s2);
+            i2 = g1 ? i1 : (g2 ? idx : i2);
+            s1 = g0 ? s0 : (g1 ? v : s1);
+            i1 = g0 ? i0 : (g1 ? idx : i1);
+            s0 = g0 ? v : s0;
+            i0 = g0 ? idx : i0;
+        };
+        for (u32 q = sq0 + lane; q < sq1; q += 64) {
+            const uint4 v4 = S4[q];
+            const u32 i = 4 * q;
+            const bool full = q < n4_full;
+            feed(__uint_as_float(v4.x), i, full || i < nb);
+            feed(__uint_as_float(v4.y), i + 1, full || i + 1 < nb);
+            feed(__uint_as_float(v4.z), i + 2, full || i + 2 < nb);
+            feed(__uint_as_float(v4.w), i + 3, full || i + 3 < nb);
+        }
+        u64 k0 = (i0 != 0xFFFFu) ? make_key(__float_as_uint(s0), i0) : 0ull;
+        u64 k1 = (i1 != 0xFFFFu) ? make_key(__float_as_uint(s1), i1) : 0ull;
+        u64 k2 = (i2 != 0xFFFFu) ? make_key(__float_as_uint(s2), i2) : 0ull;
+        u64 wkey = 0, last = 0;
+        int num = 0;
+        for (int rr = 0; rr < K; rr++) {
+            const u64 mx = group_max<64>(k0);
+            if (mx == 0) break;
+            num++;
+            last = mx;
+            if (k0 == mx) { k0 = k1; k1 = k2; k2 = 0; }
+            if ((int)lane == rr) wkey = mx;
+        }
+        const bool doubt = (num == K) ? (lost >= unord_f32((u32)(last >> 32))) : (lost > -INFINITY);
+        if (__any(doubt)) num = select_rounds64(S, nb, sq0, sq1, lane, K, wkey);
+        for (u32 q = sq0 + lane; q < sq1; q += 64) S4w[q] = reset4;
+        if ((int)lane < K) list[wave * K + lane] = ((int)lane < num) ? wkey : 0ull;
+        __syncthreads();
+        // ---- select, level 2 (wave 0): exact top-K of the NW*K wave winners, then weights and output rows ----
+        if (wave == 0) {
+            const int c = (int)NW * K;
+            u64 *win = list + ((c + 1) & ~1);
+            if ((int)lane < K) win[lane] = 0ull;
+            wave_lds_fence();
+            rank_candidates<64>(list, c, win, K, lane);
+            const u64 win_key = ((int)lane < K) ? win[lane] : 0ull;
+            const int numBest = __builtin_popcountll(__ballot(win_key != 0));
+            const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+            if (!deferred) weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // ASCII kernel for reads that contain ambiguity characters (one wave per read, sequential k-mers).
 // A1/A2/A7: AmbigSequenceKnife.java:98-272, PlacementProcess.java:1129-1236.
 // ------------------------------------------------------------------------------------------------

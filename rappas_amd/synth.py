@@ -19,6 +19,9 @@ CONFIGS = {
     "C2": (4, 10, 500, 786_432, 10_000_000, 150, 10_000_000),
     "C4": (20, 5, 200, 320_000, 3_200_000, 100, 1_000_000),
     "C5mini": (4, 12, 10_000, 1_048_576, 50_000_000, 250, 100_000),  # C5's tree/k at a DB size one test can hold
+    # C5-shaped per-read work (19 999 branches, rows of ~2 600 entries, 250 bp => H ~ 4.7e5 entries/read) with a smaller
+    # key space (k=8) so that the DB is ~1 GB instead of 200 GB: beyond the Infinity Cache, i.e. HBM-bound like C5
+    "C5s": (4, 8, 10_000, 49_152, 127_795_200, 250, 200_000),
 }
 
 

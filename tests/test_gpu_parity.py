@@ -83,8 +83,27 @@ def test_c5_large_tree_scaled(table):
             code = int(sdb.key_codes[rng.integers(0, sdb.n_keys)])
             p = int(off[r]) + int(rng.integers(0, 238))
             seq[p:p + 12] = letters[[(code >> (2 * i)) & 3 for i in range(12)]]
-    _, ref, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, table)
+    odb = O.OracleDB.from_synth(sdb)
+    _, ref, st = run_case(sdb, odb, seq, off, table)          # workgroup-per-read kernel (indexed rows)
     assert st["placed"] > 300
+    run_case(sdb, odb, seq, off, table, lanes=64)              # single-wave kernel on the same DB image
+
+
+@pytest.mark.parametrize("K", [1, 7, 16])
+def test_large_tree_long_rows_workgroup_kernel(K):
+    """C5-shaped rows (thousands of entries over 19 999 branches): every wave of the workgroup streams its branch slice."""
+    sdb = synth.make_db(4, 6, 19999, 3000, 6_000_000, seed=11)          # mean row 2 000 entries
+    seq, off = synth.make_reads(4, 60, 250, seed=17, var_len=200)
+    got, ref, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", keepAtMost=K, keepFactor=0.0 if K == 16 else 0.01)
+    assert st["placed"] >= 55
+
+
+def test_large_tree_one_workgroup_per_cu():
+    """30 000 branches: only one score vector fits a CU, the workgroup has 16 waves."""
+    sdb = synth.make_db(4, 7, 30000, 8000, 2_000_000, seed=12)
+    seq, off = synth.make_reads(4, 100, 200, seed=18)
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "hash")
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct")
 
 
 @pytest.mark.parametrize("amb", ["mean", "max"])
