@@ -249,6 +249,23 @@ def main():
             line["cpu_baseline"] = {"value": ns / cdt, "unit": "reads/s", "cores": 1, "kind": "port",
                                     "sample": f"first {ns} reads of rank 0's batch, same DB, oracle/rappas_oracle.c "
                                               f"(single thread, like the reference's placement loop), {cdt:.1f} s"}
+            # the same oracle on every host core (reads split into contiguous chunks, one thread each; ctypes drops the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            ncore = max(1, min(os.cpu_count() or 1, 64))
+            nall = min(n_reads, ns * min(ncore, 8))
+            seq_a, off_a = (seq, off) if nall == ns else unpack_to_ascii(alphabet, packed[:nall].cpu().numpy().view(np.uint32), rlen)
+            bounds = [nall * i // ncore for i in range(ncore + 1)]
+
+            def work(i):
+                a0, a1 = bounds[i], bounds[i + 1]
+                if a1 > a0:
+                    odb.place(seq_a[int(off_a[a0]):int(off_a[a1])], off_a[a0:a1 + 1] - off_a[a0], keep_at_most=K)
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(ncore) as ex:
+                list(ex.map(work, range(ncore)))
+            cdt2 = time.perf_counter() - c0
+            line["cpu_baseline_all_cores"] = {"value": nall / cdt2, "unit": "reads/s", "cores": ncore, "kind": "port",
+                                              "sample": f"first {nall} reads, {ncore} threads, {cdt2:.1f} s"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

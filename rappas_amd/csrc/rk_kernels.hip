@@ -653,6 +653,8 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         if (have) {
             R = a.lens ? a.lens[r] : a.fixed_len;
             fin = a.flags_in ? a.flags_in[r] : 0u;
+            const u32 cap_syms = (a.words_per_read * 32u) / BITS;  // never read past the packed record
+            R = R < cap_syms ? R : cap_syms;
         }
         u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
         const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
@@ -959,7 +961,9 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
     __syncthreads();
 
     for (u64 r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
-        const u32 R = a.lens ? a.lens[r] : a.fixed_len;
+        u32 R = a.lens ? a.lens[r] : a.fixed_len;
+        const u32 cap_syms = (a.words_per_read * 32u) / BITS;  // never read past the packed record
+        R = R < cap_syms ? R : cap_syms;
         const u32 fin = a.flags_in ? a.flags_in[r] : 0u;
         u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
         const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
