@@ -123,6 +123,9 @@ const char *rk_last_error(void);
 void rk_thresholds(float omega, uint32_t n_states, uint32_t k, float *thr, float *thr_log10);
 
 int rk_db_create(const rk_db_desc *desc, rk_db **out);
+/* Same argument checks and host-side image construction as rk_db_create, but no device is touched: lets the caller
+ * (or a CPU-only test) validate a DB and learn its HBM footprint / table flavour.  info may be NULL. */
+int rk_db_validate(const rk_db_desc *desc, rk_db_info *info);
 void rk_db_destroy(rk_db *db);
 int rk_db_get_info(const rk_db *db, rk_db_info *info);
 

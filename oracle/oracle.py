@@ -33,7 +33,7 @@ def load():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(SO)
+        L = C.CDLL(os.environ.get("RO_LIB") or SO)  # RO_LIB: sanitizer build (scripts/asan_host.sh)
         L.ro_thresholds.argtypes = [C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ro_max_ambig_per_mer.restype = C.c_int
         L.ro_max_ambig_per_mer.argtypes = [C.c_int, C.c_int]

@@ -49,6 +49,7 @@ EXPORTS = {
     "rk_last_error": (C.c_char_p, []),
     "rk_thresholds": (None, [C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rk_db_create": (C.c_int, [C.POINTER(rk_db_desc), C.POINTER(C.c_void_p)]),
+    "rk_db_validate": (C.c_int, [C.POINTER(rk_db_desc), C.POINTER(rk_db_info)]),
     "rk_db_destroy": (None, [C.c_void_p]),
     "rk_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(rk_db_info)]),
     "rk_place_batch": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_void_p,

@@ -152,9 +152,17 @@ extern "C" void rk_db_destroy(rk_db *db) {
     delete db;
 }
 
-extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
-    if (!d || !out) return fail(RK_ERR_INVALID, "rk_db_create: null argument");
-    *out = nullptr;
+// Validation + host-side construction of the HBM image (no HIP call in here: rk_db_validate runs it without a device).
+struct DbImage {
+    uint32_t mode = 0, bits = 0, max_len = 0;
+    bool indexed = false;
+    uint64_t n_keys = 0, n_entries = 0, blob_bytes = 0, slots = 0, hash_mask = 0;
+    std::vector<Entry> blob;
+    std::vector<uint64_t> table;
+};
+
+static int build_image(const rk_db_desc *d, DbImage &img) {
+    if (!d) return fail(RK_ERR_INVALID, "rk_db_create: null argument");
     if (d->alphabet != RK_ALPHABET_DNA && d->alphabet != RK_ALPHABET_AA)
         return fail(RK_ERR_INVALID, "rk_db_create: alphabet must be 4 (DNA) or 20 (AA), got %u", d->alphabet);
     const uint32_t bits = d->alphabet == RK_ALPHABET_DNA ? 2 : 5;
@@ -171,16 +179,12 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     if (n_entries && (!d->branch_ids || !d->scores)) return fail(RK_ERR_INVALID, "rk_db_create: null entry arrays");
     if (n_keys && d->row_offsets[0] != 0) return fail(RK_ERR_INVALID, "rk_db_create: row_offsets[0] must be 0");
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(RK_ERR_NO_DEVICE, "rk_db_create: no HIP device available (this engine has no CPU fallback)");
-    if (d->device < 0 || d->device >= ndev)
-        return fail(RK_ERR_INVALID, "rk_db_create: device %d out of range (0..%d)", d->device, ndev - 1);
-
+    img.bits = bits; img.n_keys = n_keys; img.n_entries = n_entries;
     // ---- table mode ----
     uint64_t space = 0;
     const bool space_ok = ipow_fits(d->alphabet, d->k, 1ull << 40, space);
-    uint32_t mode = d->table_mode;
+    uint32_t &mode = img.mode;
+    mode = d->table_mode;
     if (mode == RK_TABLE_AUTO) {
         // Direct addressing whenever all sigma^k codes fit 2^28 slots; DIRECT = compact 2-byte-per-k-mer blocks that
         // stay in the XCD L2s (measured on C2: 2.36e8 reads/s vs 2.18e8 with 8-byte descriptors, whose probes push the
@@ -230,6 +234,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     // i = 1..32, so a wave finds its slice of a row with two 2-byte loads.  Descriptors still point at the first
     // entry line; the other kernels never look at the index line.
     const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES;
+    img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
     uint64_t blob_units = 1;             // 64-byte units
     uint32_t max_len = 0;
@@ -251,7 +256,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     }
     const uint64_t blob_bytes = blob_units * 64;
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
-    std::vector<Entry> blob;
+    std::vector<Entry> &blob = img.blob;
     try { blob.assign(blob_bytes / 8, Entry{0xFFFFu, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
     {
         std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
@@ -289,8 +294,9 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     // DIRECT8 : one 8-byte descriptor per k-mer.
     // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
     if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32) || indexed)) mode = RK_TABLE_DIRECT8;
-    std::vector<uint64_t> table;
-    uint64_t slots = 0, hash_mask = 0;
+    std::vector<uint64_t> &table = img.table;
+    uint64_t &slots = img.slots, &hash_mask = img.hash_mask;
+    slots = 0; hash_mask = 0;
     try {
         if (mode == RK_TABLE_DIRECT) {
             slots = space;
@@ -328,6 +334,44 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     } catch (const std::bad_alloc &) {
         return fail(RK_ERR_NOMEM, "rk_db_create: host OOM building the k-mer table");
     }
+
+    img.blob_bytes = blob_bytes;
+    img.max_len = max_len;
+    return RK_OK;
+}
+
+extern "C" int rk_db_validate(const rk_db_desc *d, rk_db_info *info) {
+    DbImage img;
+    int rc = build_image(d, img);
+    if (rc) return rc;
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->alphabet = d->alphabet; info->k = d->k; info->n_branches = d->n_branches; info->table_mode = img.mode;
+        info->thr_log10 = d->thr_log10; info->thr = d->thr; info->n_keys = img.n_keys; info->n_entries = img.n_entries;
+        info->table_slots = img.slots; info->table_bytes = img.table.size() * sizeof(uint64_t); info->rows_bytes = img.blob_bytes;
+        info->bits_per_symbol = img.bits; info->max_row_len = img.max_len; info->device = -1;
+    }
+    return RK_OK;
+}
+
+extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
+    if (!d || !out) return fail(RK_ERR_INVALID, "rk_db_create: null argument");
+    *out = nullptr;
+    DbImage img;
+    {
+        int rc = build_image(d, img);  // argument errors are reported before the device is looked at
+        if (rc) return rc;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RK_ERR_NO_DEVICE, "rk_db_create: no HIP device available (this engine has no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev)
+        return fail(RK_ERR_INVALID, "rk_db_create: device %d out of range (0..%d)", d->device, ndev - 1);
+    const uint32_t mode = img.mode, bits = img.bits, max_len = img.max_len;
+    const bool indexed = img.indexed;
+    const uint64_t n_keys = img.n_keys, n_entries = img.n_entries, blob_bytes = img.blob_bytes, slots = img.slots, hash_mask = img.hash_mask;
+    std::vector<Entry> &blob = img.blob;
+    std::vector<uint64_t> &table = img.table;
 
     // ---- upload ----
     rk_db *db = new (std::nothrow) rk_db();

@@ -31,6 +31,21 @@ class Placements:
     counters: dict
 
 
+def validate_db(alphabet, k, n_branches, thr_log10, thr, key_codes, row_offsets, branch_ids, scores,
+                table_mode=RK_TABLE_AUTO, convert_uo=False):
+    """rk_db_validate: argument checks + host-side image construction, no device needed. Returns rk_db_info."""
+    lib = _lib.load()
+    key_codes = np.ascontiguousarray(key_codes, dtype=np.uint64)
+    row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+    branch_ids = np.ascontiguousarray(branch_ids, dtype=np.uint16)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    d = rk_db_desc(alphabet, int(bool(convert_uo)), k, n_branches, float(thr_log10), float(thr), key_codes.shape[0],
+                   _ptr(key_codes), _ptr(row_offsets), _ptr(branch_ids), _ptr(scores), 0, table_mode)
+    info = rk_db_info()
+    _lib.check(lib.rk_db_validate(C.byref(d), C.byref(info)))
+    return info
+
+
 class PhyloKmerDB:
     """Phylo-kmer DB resident in one GPU's HBM (open-addressed / direct table + CSR rows)."""
 

@@ -84,3 +84,60 @@ def test_product_package_does_not_import_oracle():
                 if f.endswith((".py", ".hip", ".h", ".cpp", ".c", ".hpp")):
                     txt = open(os.path.join(dp, f)).read()
                     assert "liboracle" not in txt and "rappas_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def _validate(sdb, **kw):
+    args = dict(key_codes=sdb.key_codes, row_offsets=sdb.row_offsets, branch_ids=sdb.branch_ids, scores=sdb.scores)
+    args.update(kw)
+    return ra.validate_db(sdb.alphabet, sdb.k, sdb.n_branches, sdb.thr_log10, sdb.thr, **args)
+
+
+def test_db_validate_builds_image_without_device():
+    """rk_db_validate runs the whole host-side image construction (no HIP): layout invariants of DESIGN.md section 3."""
+    sdb = synth.make_config_db("C1")
+    info = _validate(sdb)
+    assert info.table_mode == _lib.RK_TABLE_DIRECT and info.bits_per_symbol == 2 and info.device == -1
+    assert info.n_keys == sdb.n_keys and info.n_entries == sdb.n_entries
+    lens = np.diff(sdb.row_offsets.astype(np.int64))
+    assert info.max_row_len == lens.max()
+    lines = ((lens + 7) // 8).sum() + 1                     # rows padded to whole 64-byte lines + the reserved line 0
+    assert info.rows_bytes == lines * 64
+    assert info.table_bytes == ((4 ** 8 + 11) // 12) * 16   # compact table: 16 bytes per 12 k-mers
+    assert _validate(sdb, table_mode=_lib.RK_TABLE_DIRECT8).table_bytes == 4 ** 8 * 8
+    h = _validate(sdb, table_mode=_lib.RK_TABLE_HASH)
+    assert h.table_mode == _lib.RK_TABLE_HASH and h.table_slots >= 2 * sdb.n_keys and h.table_bytes == h.table_slots * 16
+    aa = synth.make_db(20, 3, 30, 500, 2000, seed=1)
+    assert _validate(aa).bits_per_symbol == 5
+    big = synth.make_db(4, 6, 19999, 300, 60000, seed=2)     # large tree: indexed rows (+1 line per row), 8-byte descriptors
+    bi = _validate(big)
+    bl = np.diff(big.row_offsets.astype(np.int64))
+    assert bi.table_mode == _lib.RK_TABLE_DIRECT8 and bi.rows_bytes == (((bl + 7) // 8).sum() + len(bl) + 1) * 64
+    long_rows = synth.make_db(4, 6, 4000, 50, 150000, seed=3)  # rows > 2040 entries do not fit the compact table
+    assert _validate(long_rows).table_mode == _lib.RK_TABLE_DIRECT8
+
+
+def test_db_validate_rejects_bad_input():
+    sdb = synth.make_db(4, 6, 31, 200, 900, seed=1)
+    bad = sdb.branch_ids.copy(); bad[1] = bad[0]
+    with pytest.raises(ra.RkError, match="repeated inside row"):
+        _validate(sdb, branch_ids=bad)
+    bad = sdb.branch_ids.copy(); bad[5] = 31
+    with pytest.raises(ra.RkError, match=">= n_branches"):
+        _validate(sdb, branch_ids=bad)
+    dup = sdb.key_codes.copy(); dup[3] = dup[2]
+    for mode in (_lib.RK_TABLE_DIRECT, _lib.RK_TABLE_DIRECT8, _lib.RK_TABLE_HASH):
+        with pytest.raises(ra.RkError, match="duplicate k-mer"):
+            _validate(sdb, key_codes=dup, table_mode=mode)
+    nan = sdb.scores.copy(); nan[0] = np.inf
+    with pytest.raises(ra.RkError, match="non-finite"):
+        _validate(sdb, scores=nan)
+    badcode = sdb.key_codes.copy(); badcode[0] = 4 ** 6
+    with pytest.raises(ra.RkError, match="invalid k-mer code"):
+        _validate(sdb, key_codes=badcode)
+    off = sdb.row_offsets.copy(); off[3] = off[2]
+    with pytest.raises(ra.RkError, match="empty row"):
+        _validate(sdb, row_offsets=off)
+    aa = synth.make_db(20, 3, 30, 100, 400, seed=1)
+    codes = aa.key_codes.copy(); codes[0] = 21            # digit 21 >= 20
+    with pytest.raises(ra.RkError, match="invalid k-mer code"):
+        _validate(aa, key_codes=codes)
