@@ -38,6 +38,7 @@ struct DbView {
     u32 k, bits, n_branches, alphabet;
     float T, P;
     u32 convert_uo;
+    u32 soa;  // large-tree (indexed) images: a row is u16 branch[len] followed by f32 score[len] (6 bytes per entry)
 };
 
 struct PlaceArgs {

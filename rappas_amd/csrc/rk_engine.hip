@@ -248,21 +248,29 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
         if (len > d->n_branches)
             return fail(RK_ERR_INVALID, "rk_db_create: row %llu has %llu entries (> n_branches)", (unsigned long long)r, (unsigned long long)len);
         if (len > max_len) max_len = (uint32_t)len;
-        const uint64_t units = (len + ROW_UNIT - 1) / ROW_UNIT;
+        uint64_t units = (len + ROW_UNIT - 1) / ROW_UNIT;  // 64-byte lines of 8 {branch, score} entries
+        uint64_t lenp = units * ROW_UNIT;
+        if (indexed) {
+            // [index line][u16 branch[lenp]][f32 score[lenp]], lenp a multiple of 32 so that the row is whole lines
+            blob_units += 1;
+            lenp = (len + 31) / 32 * 32;
+            units = lenp * 6 / 64;
+        }
         if (units > max_units) max_units = units;
-        if (indexed) blob_units += 1;  // the index line
-        desc[r] = ((blob_units * 8) << DESC_LEN_BITS) | (units * ROW_UNIT);
+        desc[r] = ((blob_units * 8) << DESC_LEN_BITS) | lenp;
         blob_units += units;
     }
     const uint64_t blob_bytes = blob_units * 64;
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
     std::vector<Entry> &blob = img.blob;
-    try { blob.assign(blob_bytes / 8, Entry{0xFFFFu, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
+    try { blob.assign(blob_bytes / 8, indexed ? Entry{0xFFFFFFFFu, 0.0f} : Entry{0xFFFFu, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
     {
         std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
         for (uint64_t r = 0; r < n_keys; r++) {
             uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
             Entry *ep = blob.data() + (desc[r] >> DESC_LEN_BITS);
+            std::vector<Entry> tmp;
+            if (indexed) { tmp.resize(len); ep = tmp.data(); }
             for (uint64_t i = 0; i < len; i++) {
                 uint16_t x = d->branch_ids[b + i];
                 float v = d->scores[b + i];
@@ -275,12 +283,20 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
             }
             if (indexed) {
                 std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
-                uint16_t *split = (uint16_t *)(ep - ROW_UNIT);  // the 64-byte line in front of the row
+                unsigned char *row = (unsigned char *)(blob.data() + (desc[r] >> DESC_LEN_BITS));
+                const uint64_t lenp = (uint32_t)desc[r] & DESC_LEN_MASK;
+                uint16_t *split = (uint16_t *)(row - 64);  // the 64-byte line in front of the row
+                uint16_t *bp = (uint16_t *)row;
+                float *sp = (float *)(row + 2 * lenp);
                 uint64_t e = 0;
                 for (uint32_t i = 1; i <= 32; i++) {
                     const uint32_t bound = (uint32_t)(((uint64_t)i * d->n_branches) / 32);
                     while (e < len && ep[e].branch < bound) e++;
                     split[i - 1] = (uint16_t)e;
+                }
+                for (uint64_t i = 0; i < lenp; i++) {
+                    bp[i] = i < len ? (uint16_t)ep[i].branch : (uint16_t)0xFFFFu;  // padding = skip entries
+                    sp[i] = i < len ? ep[i].score : 0.0f;
                 }
             }
         }
@@ -422,6 +438,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     db->view.rows = (const unsigned char *)db->d_rows;
     db->view.k = d->k; db->view.bits = bits; db->view.n_branches = d->n_branches; db->view.alphabet = d->alphabet;
     db->view.T = d->thr_log10; db->view.P = d->thr; db->view.convert_uo = d->convert_uo;
+    db->view.soa = indexed ? 1u : 0u;
     *out = db;
     return RK_OK;
 }
@@ -443,6 +460,8 @@ extern "C" int rk_set_lanes_per_read(rk_db *db, uint32_t lanes) {
     if (!db) return fail(RK_ERR_INVALID, "rk_set_lanes_per_read: null db");
     if (lanes != 0 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64)
         return fail(RK_ERR_INVALID, "rk_set_lanes_per_read: lanes must be 0 (auto), 8, 16, 32 or 64");
+    if (lanes != 0 && db->indexed)
+        return fail(RK_ERR_UNSUPPORTED, "rk_set_lanes_per_read: large-tree images (n_branches > %u) always use the workgroup-per-read kernel", RK_WG_MIN_BRANCHES);
     db->lanes_per_read = lanes;
     return RK_OK;
 }

@@ -79,6 +79,21 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// entry e of the row a descriptor points at, for either row layout (8-byte {branch, score} pairs, or -- large-tree
+// images -- a u16 branch array followed by an f32 score array)
+__device__ __forceinline__ void load_entry(const DbView &db, u64 desc, u32 e, u32 &br, float &sc) {
+    const unsigned char *base = db.rows + ((desc >> DESC_LEN_BITS) << 3);
+    if (db.soa) {
+        const u32 len = (u32)desc & DESC_LEN_MASK;
+        br = ((const unsigned short *)base)[e];
+        sc = ((const float *)(base + 2 * (size_t)len))[e];
+    } else {
+        const Entry en = ((const Entry *)base)[e];
+        br = en.branch;
+        sc = en.score;
+    }
+}
+
 // k-mer code at symbol position j of a packed record (symbol i at bits [i*BITS, (i+1)*BITS) of the
 // little-endian bit string).  DNA: this integer IS the reference key (compressMer bytes little-endian,
 // DNAStatesShifted.java:115-143).  AA: sum state_i << 5i (compressMer = identity, AAStates.java:195-197).
@@ -838,20 +853,24 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
                                                 const unsigned char *rows, float QT, float T) {
     typedef typename OffsetT<WIDE>::type off_t;
     // ---- phase A: this wave's slice [start, start + n) of every row of the batch (row h lives in lane h%64, slot h/64)
-    off_t start[WG_SLOTS];
+    // rows of an indexed image: [64-byte index line][u16 branch[len]][f32 score[len]], len a multiple of 32
+    off_t start[WG_SLOTS];   // byte offset of the slice's first branch id
+    off_t sstart[WG_SLOTS];  // byte offset of the slice's first score
     u32 nn[WG_SLOTS];
 #pragma unroll
     for (int sl = 0; sl < WG_SLOTS; sl++) {
         const int h = (int)lane + 64 * sl;
         const bool have = h < cnt;
         const u64 d = list[have ? h : 0];
-        const off_t off = (off_t)(d >> DESC_LEN_BITS) << 3;  // byte offset of the first entry line
+        const off_t off = (off_t)(d >> DESC_LEN_BITS) << 3;  // byte offset of the branch array
+        const u32 lenp = (u32)d & DESC_LEN_MASK;
         const unsigned short *split = (const unsigned short *)(rows + off - 64);
         const u32 lo_raw = split[q_lo ? q_lo - 1 : 0];
         const u32 hi = split[q_hi - 1];
         const u32 lo = q_lo ? lo_raw : 0u;
         nn[sl] = have ? hi - lo : 0u;
-        start[sl] = off + (off_t)lo * 8;
+        start[sl] = off + (off_t)lo * 2;
+        sstart[sl] = off + (off_t)lenp * 2 + (off_t)lo * 4;
     }
     u64 mk[WG_SLOTS];
 #pragma unroll
@@ -860,9 +879,9 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
     int sl = 0;
     u64 m = mk[0];
     int rem = 0;
-    off_t cur = 0;
+    off_t cur = 0, scur = 0;
     bool done = false;
-    const u32 lane8 = lane * 8;
+    const u32 lane2 = lane * 2, lane4 = lane * 4;
     u32 br[U];
     float sc[U];
     auto gen = [&](u32 &b, float &v) {
@@ -875,13 +894,18 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
                 const int l = __builtin_ctzll(m);
                 m &= m - 1;
                 const off_t st = sl == 0 ? start[0] : (sl == 1 ? start[1] : (sl == 2 ? start[2] : start[3]));
+                const off_t ss = sl == 0 ? sstart[0] : (sl == 1 ? sstart[1] : (sl == 2 ? sstart[2] : sstart[3]));
                 const u32 n_ = sl == 0 ? nn[0] : (sl == 1 ? nn[1] : (sl == 2 ? nn[2] : nn[3]));
                 if (WIDE) {
                     const u32 lo32 = (u32)__builtin_amdgcn_readlane((int)(u32)st, l);
                     const u32 hi32 = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)st >> 32), l);
                     cur = (off_t)(((u64)hi32 << 32) | lo32);
+                    const u32 slo = (u32)__builtin_amdgcn_readlane((int)(u32)ss, l);
+                    const u32 shi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)ss >> 32), l);
+                    scur = (off_t)(((u64)shi << 32) | slo);
                 } else {
                     cur = (off_t)(u32)__builtin_amdgcn_readlane((int)(u32)st, l);
+                    scur = (off_t)(u32)__builtin_amdgcn_readlane((int)(u32)ss, l);
                 }
                 rem = __builtin_amdgcn_readlane((int)n_, l);
             } else {
@@ -889,12 +913,13 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
             }
         }
         const bool ok = (int)lane < rem;
-        const off_t eo = ok ? (off_t)(cur + lane8) : (off_t)0;
-        const uint2 e = *(const uint2 *)(rows + eo);
-        b = e.x;
-        v = __uint_as_float(e.y);
+        const off_t bo = ok ? (off_t)(cur + lane2) : (off_t)0;  // lanes without an entry read the all-0xFF line 0: "skip"
+        const off_t so = ok ? (off_t)(scur + lane4) : (off_t)0;
+        b = *(const unsigned short *)(rows + bo);
+        v = *(const float *)(rows + so);
         rem -= 64;
-        cur += 512;
+        cur += 128;
+        scur += 256;
     };
 #pragma unroll
     for (int u = 0; u < U; u++) gen(br[u], sc[u]);
@@ -1078,10 +1103,11 @@ struct AmbArgs {
 template <int BITS, int TM>
 __device__ __forceinline__ void amb_apply_plain(const DbView &db, u32 *S, u64 desc, u32 lane, float QT, float T) {
     u32 len = (u32)desc & DESC_LEN_MASK;
-    const Entry *ep = (const Entry *)(db.rows + ((desc >> DESC_LEN_BITS) << 3));
     for (u32 e = lane; e < len; e += 64) {
-        const Entry en = ep[e];
-        if (en.branch != 0xFFFFu) apply_entry_masked(S, en.branch, en.score, QT, T);  // rows are padded with skip entries
+        u32 xb;
+        float v;
+        load_entry(db, desc, e, xb, v);
+        if (xb != 0xFFFFu) apply_entry_masked(S, xb, v, QT, T);  // rows are padded with skip entries
     }
 }
 
@@ -1150,11 +1176,12 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         u64 desc = lookup_desc<BITS, TM>(a.db, cw);
                         u32 len = (u32)desc & DESC_LEN_MASK;
                         if (!len) continue;
-                        const Entry *ep = (const Entry *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
-                            const u32 x = ep[e].branch - lo;
+                            u32 xb0;
+                            float v;
+                            load_entry(a.db, desc, e, xb0, v);
+                            const u32 x = xb0 - lo;
                             if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around, and pad entries)
-                            float v = ep[e].score;
                             u32 c = Camb[x];
                             Camb[x] = c + 1;
                             if (m.amb_mode == RK_AMB_MEAN) {
@@ -1174,9 +1201,10 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         u64 desc = lookup_desc<BITS, TM>(a.db, cw);
                         u32 len = (u32)desc & DESC_LEN_MASK;
                         if (!len) continue;
-                        const Entry *ep = (const Entry *)(a.db.rows + ((desc >> DESC_LEN_BITS) << 3));
                         for (u32 e = lane; e < len; e += 64) {
-                            const u32 xb = ep[e].branch;
+                            u32 xb;
+                            float vunused;
+                            load_entry(a.db, desc, e, xb, vunused);
                             const u32 x = xb - lo;
                             if (x >= chunk) continue;  // also skips pad entries (0xFFFF >= any chunk window)
                             u32 c = Camb[x];

@@ -111,7 +111,8 @@ def test_db_validate_builds_image_without_device():
     big = synth.make_db(4, 6, 19999, 300, 60000, seed=2)     # large tree: indexed rows (+1 line per row), 8-byte descriptors
     bi = _validate(big)
     bl = np.diff(big.row_offsets.astype(np.int64))
-    assert bi.table_mode == _lib.RK_TABLE_DIRECT8 and bi.rows_bytes == (((bl + 7) // 8).sum() + len(bl) + 1) * 64
+    # [index line][u16 branch[lenp]][f32 score[lenp]] with lenp padded to 32 entries: 6 bytes per entry
+    assert bi.table_mode == _lib.RK_TABLE_DIRECT8 and bi.rows_bytes == ((((bl + 31) // 32 * 32) * 6 // 64).sum() + len(bl) + 1) * 64
     long_rows = synth.make_db(4, 6, 4000, 50, 150000, seed=3)  # rows > 2040 entries do not fit the compact table
     assert _validate(long_rows).table_mode == _lib.RK_TABLE_DIRECT8
 
