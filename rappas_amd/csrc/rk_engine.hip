@@ -640,9 +640,15 @@ static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hip
     uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
     if (blocks > groups) blocks = groups;
     if (!blocks) return RK_OK;
-    auto kern = place_ascii_kernel<BITS, TM>;
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
+    if (db->indexed) {
+        auto kern = place_ascii_kernel<BITS, TM, true>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
+    } else {
+        auto kern = place_ascii_kernel<BITS, TM, false>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
+    }
     HIP_TRY(hipGetLastError());
     return RK_OK;
 }

@@ -205,16 +205,17 @@ struct Cursor {
     typedef typename OffsetT<WIDE>::type off_t;
     int h;      // index of the current row in the hit list
     int rem;    // entries of the current row not yet issued (<= 0: fetch the next row)
-    off_t cur;  // byte offset of the next chunk of the current row
+    off_t cur;  // byte offset of the next chunk of the current row (SOA: of its branch ids)
+    off_t scur; // SOA only: byte offset of the next chunk's scores
     u64 dn;     // list[min(h + 1, cnt)], fetched one step ahead so its LDS latency is off the critical path
 };
 
 // Branch-free on purpose: every lane always issues its row load (lanes without an entry read the reserved entry
 // at blob offset 0, whose branch id 0xFFFF means "skip"), and nothing selects on a loaded value here, so the
 // compiler counts outstanding loads exactly (s_waitcnt vmcnt(N)) and the register ring keeps U chunks in flight
-// per lane.  list[cnt] must be a zero descriptor (sentinel).
-template <int G, bool WIDE>
-__device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, int cnt, u32 li8, int li,
+// per lane.  list[cnt] must be a zero descriptor (sentinel).  SOA: rows are u16 branch[len] | f32 score[len].
+template <int G, bool WIDE, bool SOA>
+__device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, int cnt, u32 li, int lii,
                                              const unsigned char *rows, u32 &br, float &sc) {
     typedef typename OffsetT<WIDE>::type off_t;
     const bool need = c.rem <= 0;
@@ -228,20 +229,24 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
     c.h = hn;
     c.rem = need ? (int)len : c.rem;
     c.cur = need ? off : c.cur;
-    const bool ok = li < c.rem;
-    off_t eo = ok ? (off_t)(c.cur + li8) : (off_t)0;
-    if (RK_ABLATE & 16) eo = 0;  // timing-only: every row load reads the reserved "skip" entry
-#if RK_ROW_NT
-    const u64 ev = __builtin_nontemporal_load((const u64 *)(rows + eo));  // rows are read once: do not keep them in L2
-    br = (u32)ev;
-    sc = __uint_as_float((u32)(ev >> 32));
-#else
-    const uint2 e = *(const uint2 *)(rows + eo);
-    br = e.x;
-    sc = __uint_as_float(e.y);
-#endif
+    if (SOA) c.scur = need ? (off_t)(off + 2 * (off_t)len) : c.scur;
+    const bool ok = lii < c.rem;
+    if (SOA) {
+        const off_t bo = ok ? (off_t)(c.cur + 2 * li) : (off_t)0;
+        const off_t so = ok ? (off_t)(c.scur + 4 * li) : (off_t)0;
+        br = *(const unsigned short *)(rows + bo);
+        sc = *(const float *)(rows + so);
+        c.cur += 2 * G;
+        c.scur += 4 * G;
+    } else {
+        off_t eo = ok ? (off_t)(c.cur + 8 * li) : (off_t)0;
+        if (RK_ABLATE & 16) eo = 0;  // timing-only: every row load reads the reserved "skip" entry
+        const uint2 e = *(const uint2 *)(rows + eo);
+        br = e.x;
+        sc = __uint_as_float(e.y);
+        c.cur += 8 * G;
+    }
     c.rem -= G;
-    c.cur += 8 * G;
 }
 
 // S[x] update of PlacementProcess.java:726-733: first touch seeds fl(Q*T), then S = fl(S + fl(v - T)).
@@ -267,22 +272,21 @@ __device__ __forceinline__ void apply_entry_masked(u32 *S, u32 br, float sc, flo
     S[br] = __float_as_uint(nw);
 }
 
-template <int G, int U, bool WIDE>
+template <int G, int U, bool WIDE, bool SOA = false>
 __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list, int cnt, u32 li,
                                                 const unsigned char *rows, float QT, float T) {
     Cursor<WIDE> c;
-    c.h = -1; c.rem = 0; c.cur = 0;
+    c.h = -1; c.rem = 0; c.cur = 0; c.scur = 0;
     c.dn = list[0];
-    const u32 li8 = li * 8;
     u32 br[U];
     float sc[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) cursor_issue<G, WIDE>(c, list, cnt, li8, (int)li, rows, br[u], sc[u]);
+    for (int u = 0; u < U; u++) cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u]);
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             apply_entry(S, nb, br[u], sc[u], QT, T);
-            cursor_issue<G, WIDE>(c, list, cnt, li8, (int)li, rows, br[u], sc[u]);
+            cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u]);
         }
         if (!__any(c.h < cnt)) break;
     }
@@ -1088,6 +1092,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
 // A1/A2/A7: AmbigSequenceKnife.java:98-272, PlacementProcess.java:1129-1236.
 // ------------------------------------------------------------------------------------------------
 constexpr int ASCII_LIST_CAP = 160;
+constexpr int RK_ASCII_RING = 8;
 
 struct AmbArgs {
     const unsigned char *ascii;
@@ -1100,18 +1105,145 @@ struct AmbArgs {
     u32 amb_chunk;  // branches covered by the LDS Samb/Camb windows per pass (== s_stride when everything fits)
 };
 
+// One ambiguous k-mer (exactly one ambiguous position p of class cls): PlacementProcess.java:1129-1236.
+// Alternatives are looked up one after the other into the LDS windows Samb/Camb (branch-range passes when the tree
+// does not fit one window), then folded into S.
 template <int BITS, int TM>
-__device__ __forceinline__ void amb_apply_plain(const DbView &db, u32 *S, u64 desc, u32 lane, float QT, float T) {
-    u32 len = (u32)desc & DESC_LEN_MASK;
-    for (u32 e = lane; e < len; e += 64) {
-        u32 xb;
-        float v;
-        load_entry(db, desc, e, xb, v);
-        if (xb != 0xFFFFu) apply_entry_masked(S, xb, v, QT, T);  // rows are padded with skip entries
+__device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &m, u32 *S, float *Samb, u32 *Camb,
+                                             u32 chunk, u64 code, u32 p, u32 cls, u32 lane, float QT) {
+    const u32 nb = a.db.n_branches;
+    const float T = a.db.T, P = a.db.P;
+    const u32 W = m.alt_count[cls];
+    if (W <= 4 && chunk >= nb) {
+        // fast path (DNA: <= 4 alternatives; one Samb/Camb window covers the tree): the alternatives' descriptors are
+        // looked up together and, when every row fits the wave, their entries are loaded once into registers; the
+        // per-branch updates still run alternative by alternative, in the reference's order
+        u64 d[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            d[w] = ((u32)w < W) ? lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p))) : 0ull;
+        const u32 maxlen = max(max((u32)d[0] & DESC_LEN_MASK, (u32)d[1] & DESC_LEN_MASK),
+                               max((u32)d[2] & DESC_LEN_MASK, (u32)d[3] & DESC_LEN_MASK));
+        if (maxlen <= 64) {
+            u32 xb[4];
+            float v[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                xb[w] = 0xFFFFu;
+                v[w] = 0.0f;
+                if (lane < ((u32)d[w] & DESC_LEN_MASK)) load_entry(a.db, d[w], lane, xb[w], v[w]);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) {  // pass 1 (:1139-1157 / :1198-1219)
+                if (xb[w] != 0xFFFFu) {
+                    const u32 x = xb[w];
+                    const u32 c = Camb[x];
+                    Camb[x] = c + 1;
+                    if (m.amb_mode == RK_AMB_MEAN) {
+                        Samb[x] = (float)((double)Samb[x] + pow(10.0, (double)v[w]));
+                    } else {
+                        const float cur = Samb[x];
+                        Samb[x] = (c == 0 || v[w] > cur) ? v[w] : cur;
+                    }
+                }
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) {  // pass 2 (:1161-1172 / :1223-1233)
+                if (xb[w] != 0xFFFFu) {
+                    const u32 x = xb[w];
+                    const u32 c = Camb[x];
+                    if (c != 0) {
+                        const u32 old = S[x];
+                        const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+                        float nw;
+                        if (m.amb_mode == RK_AMB_MEAN) {
+                            const float missing = (float)(int)(W - c);
+                            const float pad = missing * P;
+                            const float tot = Samb[x] + pad;
+                            const float avg = tot / (float)(int)W;
+                            nw = (float)((double)base + (log10((double)avg) - (double)T));
+                        } else {
+                            const float dd = Samb[x] - T;
+                            nw = base + dd;
+                        }
+                        S[x] = __float_as_uint(nw);
+                        Camb[x] = 0;
+                        Samb[x] = 0.0f;
+                    }
+                }
+                wave_lds_fence();
+            }
+            return;
+        }
+    }
+    for (u32 lo = 0; lo < nb; lo += chunk) {
+        // pass 1: gather alternatives into Samb / Camb (sequential over alternatives)
+        for (u32 w = 0; w < W; w++) {
+            u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
+            u64 desc = lookup_desc<BITS, TM>(a.db, cw);
+            u32 len = (u32)desc & DESC_LEN_MASK;
+            if (!len) continue;
+            for (u32 e = lane; e < len; e += 64) {
+                u32 xb0;
+                float v;
+                load_entry(a.db, desc, e, xb0, v);
+                const u32 x = xb0 - lo;
+                if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around, and pad entries)
+                u32 c = Camb[x];
+                Camb[x] = c + 1;
+                if (m.amb_mode == RK_AMB_MEAN) {
+                    // S_amb[x] += Math.pow(10, v)  (float += double, :1155)
+                    Samb[x] = (float)((double)Samb[x] + pow(10.0, (double)v));
+                } else {
+                    float cur = Samb[x];
+                    Samb[x] = (c == 0 || v > cur) ? v : cur;  // :1212-1217
+                }
+            }
+            wave_lds_fence();
+        }
+        // pass 2: fold into S; the first alternative row that lists x does it (per-branch updates are independent,
+        // so the L_amb visiting order does not change any S[x])
+        for (u32 w = 0; w < W; w++) {
+            u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
+            u64 desc = lookup_desc<BITS, TM>(a.db, cw);
+            u32 len = (u32)desc & DESC_LEN_MASK;
+            if (!len) continue;
+            for (u32 e = lane; e < len; e += 64) {
+                u32 xb;
+                float vunused;
+                load_entry(a.db, desc, e, xb, vunused);
+                const u32 x = xb - lo;
+                if (x >= chunk) continue;  // also skips pad entries (0xFFFF >= any chunk window)
+                u32 c = Camb[x];
+                if (c != 0) {
+                    u32 old = S[xb];
+                    float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+                    float nw;
+                    if (m.amb_mode == RK_AMB_MEAN) {
+                        float missing = (float)(int)(W - c);  // :1168, all float32
+                        float pad = missing * P;
+                        float tot = Samb[x] + pad;
+                        float avg = tot / (float)(int)W;
+                        nw = (float)((double)base + (log10((double)avg) - (double)T));  // :1169
+                    } else {
+                        float d = Samb[x] - T;  // :1230
+                        nw = base + d;
+                    }
+                    S[xb] = __float_as_uint(nw);
+                    Camb[x] = 0;
+                    Samb[x] = 0.0f;
+                }
+            }
+            wave_lds_fence();
+        }
     }
 }
 
-template <int BITS, int TM>
+// One wave per read.  Lane <-> k-mer position, 64 positions per block: the unambiguous positions of a block are
+// looked up together and their hit rows go through the same ordered row cursor / register ring as in the packed
+// kernel; an ambiguous position first flushes the pending rows (k-mer order!) and is then handled on its own.
+template <int BITS, int TM, bool SOA>
 __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m) {
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
@@ -1119,15 +1251,15 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     u32 *S = lds;
     // Samb/Camb cover branches [lo, lo + amb_chunk) per pass; large trees take several passes over the alternatives
     const u32 chunk = m.amb_chunk;
-    u64 *clist = (u64 *)(lds + a.s_stride);  // ASCII_LIST_CAP candidate slots for select_topk
+    u64 *clist = (u64 *)(lds + a.s_stride);  // ASCII_LIST_CAP slots: hit list, then candidate list of select_topk
     float *Samb = (float *)(lds + a.s_stride + 2 * ASCII_LIST_CAP);
     u32 *Camb = lds + a.s_stride + 2 * ASCII_LIST_CAP + chunk;
     const u32 k = a.db.k;
-    const float T = a.db.T, P = a.db.P;
+    const float T = a.db.T;
+    const int cap = ASCII_LIST_CAP - 1;
     for (u32 i = lane; i < a.s_stride; i += 64) S[i] = S_UNTOUCHED;
     for (u32 i = lane; i < chunk; i += 64) { Samb[i] = 0.0f; Camb[i] = 0; }
     wave_lds_fence();
-    const u64 kmask = (k * BITS >= 64) ? ~0ull : ((1ull << (k * BITS)) - 1);
 
     for (u64 r0 = (u64)blockIdx.x * 64; r0 < a.n_reads; r0 += (u64)gridDim.x * 64) {
         // each lane inspects one read's flag; the wave then serves the flagged ones in turn
@@ -1145,102 +1277,64 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
             if (R < k) flags |= RK_FLAG_TOO_SHORT;
             const u32 Q = R >= k ? R - k + 1 : 0;
             const float QT = (float)(int)Q * T;
-            // rolling window state (identical in every lane)
-            u64 code = 0;   // ambiguous positions contribute state 0
-            u32 ambmask = 0;  // bit i <=> window position i is ambiguous
-            for (u32 i = 0; i + 1 < k && i < R; i++) {
-                u32 c = m.char_table[s[i]];
-                u32 st = (c & 0x80) ? 0u : c;
-                code |= (u64)st << (BITS * i);
-                ambmask |= ((c >> 7) & 1u) << i;
-            }
-            for (u32 j = 0; j < Q; j++) {
-                {
-                    u32 c = m.char_table[s[j + k - 1]];
-                    u32 st = (c & 0x80) ? 0u : c;
-                    code |= (u64)st << (BITS * (k - 1));
-                    ambmask |= ((c >> 7) & 1u) << (k - 1);
+            int cnt = 0;
+            auto flush = [&]() {
+                if (cnt > 0) {
+                    if (lane == 0) clist[cnt] = 0;  // sentinel: an empty row ends the cursor
+                    wave_lds_fence();
+                    accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T);
+                    wave_lds_fence();
+                    cnt = 0;
                 }
-                const u32 namb = __builtin_popcount(ambmask);
-                if (namb == 0) {
-                    u64 desc = lookup_desc<BITS, TM>(a.db, code);
-                    if ((u32)desc & DESC_LEN_MASK) amb_apply_plain<BITS, TM>(a.db, S, desc, lane, QT, T);
-                } else if (namb <= m.max_amb && namb == 1 && m.amb_mode != RK_AMB_SKIP) {
-                    const u32 p = __builtin_ctz(ambmask);
-                    const u32 cls = m.char_table[s[j + p]] & 0x7F;
-                    const u32 W = m.alt_count[cls];
-                    for (u32 lo = 0; lo < nb; lo += chunk) {
-                    // pass 1: gather alternatives into Samb / Camb (sequential over alternatives)
-                    for (u32 w = 0; w < W; w++) {
-                        u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
-                        u64 desc = lookup_desc<BITS, TM>(a.db, cw);
-                        u32 len = (u32)desc & DESC_LEN_MASK;
-                        if (!len) continue;
-                        for (u32 e = lane; e < len; e += 64) {
-                            u32 xb0;
-                            float v;
-                            load_entry(a.db, desc, e, xb0, v);
-                            const u32 x = xb0 - lo;
-                            if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around, and pad entries)
-                            u32 c = Camb[x];
-                            Camb[x] = c + 1;
-                            if (m.amb_mode == RK_AMB_MEAN) {
-                                // S_amb[x] += Math.pow(10, v)  (float += double, :1155)
-                                Samb[x] = (float)((double)Samb[x] + pow(10.0, (double)v));
-                            } else {
-                                float cur = Samb[x];
-                                Samb[x] = (c == 0 || v > cur) ? v : cur;  // :1212-1217
-                            }
-                        }
-                        wave_lds_fence();
+            };
+            for (u32 j0 = 0; j0 < Q; j0 += 64) {
+                const u32 j = j0 + lane;
+                const bool inr = j < Q;
+                u64 code = 0;      // ambiguous positions contribute state 0
+                u32 ambmask = 0;   // bit i <=> window position i is ambiguous
+                if (inr) {
+                    for (u32 i = 0; i < k; i++) {
+                        const u32 c = m.char_table[s[j + i]];
+                        code |= (u64)((c & 0x80) ? 0u : c) << (BITS * i);
+                        ambmask |= ((c >> 7) & 1u) << i;
                     }
-                    // pass 2: fold into S; the first alternative row that lists x does it (per-branch updates
-                    // are independent, so the L_amb visiting order does not change any S[x])
-                    for (u32 w = 0; w < W; w++) {
-                        u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
-                        u64 desc = lookup_desc<BITS, TM>(a.db, cw);
-                        u32 len = (u32)desc & DESC_LEN_MASK;
-                        if (!len) continue;
-                        for (u32 e = lane; e < len; e += 64) {
-                            u32 xb;
-                            float vunused;
-                            load_entry(a.db, desc, e, xb, vunused);
-                            const u32 x = xb - lo;
-                            if (x >= chunk) continue;  // also skips pad entries (0xFFFF >= any chunk window)
-                            u32 c = Camb[x];
-                            if (c != 0) {
-                                u32 old = S[xb];
-                                float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
-                                float nw;
-                                if (m.amb_mode == RK_AMB_MEAN) {
-                                    float missing = (float)(int)(W - c);  // :1168, all float32
-                                    float pad = missing * P;
-                                    float tot = Samb[x] + pad;
-                                    float avg = tot / (float)(int)W;
-                                    nw = (float)((double)base + (log10((double)avg) - (double)T));  // :1169
-                                } else {
-                                    float d = Samb[x] - T;  // :1230
-                                    nw = base + d;
-                                }
-                                S[xb] = __float_as_uint(nw);
-                                Camb[x] = 0;
-                                Samb[x] = 0.0f;
-                            }
-                        }
-                        wave_lds_fence();
-                    }
-                    }  // branch-range passes
                 }
-                // slide
-                code >>= BITS;
-                ambmask >>= 1;
+                u64 desc = 0;
+                if (inr && ambmask == 0) desc = lookup_desc<BITS, TM>(a.db, code);
+                const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
+                u64 amb_b = __ballot(inr && ambmask != 0);
+                const u64 hit_b = __ballot(hit);
+                u32 p0 = 0;
+                while (true) {  // wave-uniform: runs of unambiguous positions separated by ambiguous ones
+                    const u32 na = amb_b ? (u32)__builtin_ctzll(amb_b) : 64u;
+                    const u64 below_na = na >= 64 ? ~0ull : ((1ull << na) - 1);
+                    const u64 hb = hit_b & below_na & ~((1ull << p0) - 1);
+                    const int nh = __builtin_popcountll(hb);
+                    if (cnt + nh > cap) flush();
+                    if ((hb >> lane) & 1ull) clist[cnt + __builtin_popcountll(hb & ((1ull << lane) - 1))] = desc;
+                    cnt += nh;
+                    if (na >= 64) break;
+                    flush();  // everything before the ambiguous k-mer must be applied first
+                    const u32 maskA = (u32)__builtin_amdgcn_readlane((int)ambmask, (int)na);
+                    const u32 clo = (u32)__builtin_amdgcn_readlane((int)(u32)code, (int)na);
+                    const u32 chi = (u32)__builtin_amdgcn_readlane((int)(u32)(code >> 32), (int)na);
+                    const u64 codeA = ((u64)chi << 32) | clo;
+                    if (__builtin_popcount(maskA) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP) {
+                        const u32 p = __builtin_ctz(maskA);
+                        const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
+                        amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT);
+                    }
+                    amb_b &= amb_b - 1;
+                    p0 = na + 1;
+                    if (p0 >= 64) break;
+                }
             }
+            flush();
             wave_lds_fence();
             u64 win_key;
             int numBest = select_topk<64>(S, nb, lane, 0u, (int)a.keep_at_most, clist, ASCII_LIST_CAP, win_key);
             wave_lds_fence();
             weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
-            (void)kmask;
         }
     }
 }
