@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -108,6 +109,36 @@ static void build_alphabet(uint32_t alphabet, bool convert_uo, Alphabet &A) {
 // ------------------------------------------------------------------------------------------------
 // DB object
 // ------------------------------------------------------------------------------------------------
+namespace {
+struct GrowBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return RK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        return RK_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return (T *)p; }
+};
+}  // namespace
+
+struct rk_workspace {
+    GrowBuf ascii, off, packed, lens, flags, nrows, branch, score, lwr, oflags;
+    hipStream_t stream = nullptr;
+    std::vector<uint64_t> host_off;
+    void release() {
+        for (GrowBuf *b : {&ascii, &off, &packed, &lens, &flags, &nrows, &branch, &score, &lwr, &oflags}) b->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
 struct rk_db {
     rk_db_info info{};
     uint32_t convert_uo = 0;
@@ -120,7 +151,9 @@ struct rk_db {
     bool indexed = false;              // rows carry an index line (large trees, place_wg_kernel)
     int cu_count = 256;
     size_t lds_per_cu = 160 * 1024;
-    hipStream_t stream = nullptr;      // host-path stream
+    hipStream_t stream = nullptr;      // spare stream
+    std::mutex host_mutex;             // rk_place_batch (host path) owns the workspaces below
+    rk_workspace ws[2];                // device buffers + stream per in-flight chunk (grow-only)
     std::string kernel_name;
 };
 
@@ -148,6 +181,7 @@ extern "C" void rk_db_destroy(rk_db *db) {
     if (db->d_rows) (void)hipFree(db->d_rows);
     if (db->d_alpha) (void)hipFree(db->d_alpha);
     if (db->stream) (void)hipStreamDestroy(db->stream);
+    for (rk_workspace &w : db->ws) w.release();
     if (prev >= 0) (void)hipSetDevice(prev);
     delete db;
 }
@@ -764,17 +798,9 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
 }
 
 // ------------------------------------------------------------------------------------------------
-// host-buffer entry point
+// host-buffer entry point: chunked, two workspaces on two streams so that the upload of chunk c+1 overlaps the
+// kernels / download of chunk c; device buffers are kept (grow-only) in the rk_db between calls
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
-    template <class T> T *as() { return (T *)p; }
-};
-}  // namespace
-
 extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                               const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
     if (!db || !out) return fail(RK_ERR_INVALID, "rk_place_batch: null argument");
@@ -786,12 +812,16 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
     if (!out->n_rows || !out->branch || !out->score || !out->lwr || !out->flags) return fail(RK_ERR_INVALID, "rk_place_batch: null result array");
     for (uint64_t r = 0; r < n_reads; r++)
         if (seq_off[r + 1] < seq_off[r]) return fail(RK_ERR_INVALID, "rk_place_batch: seq_off not monotone at read %llu", (unsigned long long)r);
+    std::lock_guard<std::mutex> lock(db->host_mutex);  // the two workspaces belong to the db: one host call at a time
     HIP_TRY(hipSetDevice(db->info.device));
     const uint32_t K = p->keep_at_most;
-    const uint64_t max_chunk_reads = 1ull << 20, max_chunk_bytes = 256ull << 20;
-    hipStream_t s = db->stream;
+    const uint64_t max_chunk_reads = 1ull << 19, max_chunk_bytes = 128ull << 20;
+    for (rk_workspace &w : db->ws)
+        if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     uint64_t r0 = 0;
-    while (r0 < n_reads) {
+    unsigned chunk_no = 0;
+    int status = RK_OK;
+    while (r0 < n_reads && status == RK_OK) {
         uint64_t r1 = r0, max_len = 0;
         while (r1 < n_reads && r1 - r0 < max_chunk_reads && (seq_off[r1 + 1] - seq_off[r0] <= max_chunk_bytes || r1 == r0)) {
             uint64_t L = seq_off[r1 + 1] - seq_off[r1];
@@ -799,38 +829,53 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
             r1++;
         }
         const uint64_t n = r1 - r0, nbytes = seq_off[r1] - seq_off[r0];
-        if (max_len > 0x7FFFFFFFull / 8) return fail(RK_ERR_UNSUPPORTED, "rk_place_batch: read longer than 2^28 symbols");
+        if (max_len > 0x7FFFFFFFull / 8) { status = fail(RK_ERR_UNSUPPORTED, "rk_place_batch: read longer than 2^28 symbols"); break; }
         const uint32_t wpr = rk_packed_words(db, (uint32_t)max_len);
-        std::vector<uint64_t> off(n + 1);
-        for (uint64_t i = 0; i <= n; i++) off[i] = seq_off[r0 + i] - seq_off[r0];
-        DevBuf d_ascii, d_off, d_packed, d_lens, d_flags, d_nrows, d_branch, d_score, d_lwr, d_oflags;
-        HIP_TRY(d_ascii.alloc(nbytes));
-        HIP_TRY(d_off.alloc((n + 1) * 8));
-        HIP_TRY(d_packed.alloc(n * wpr * 4));
-        HIP_TRY(d_lens.alloc(n * 4));
-        HIP_TRY(d_flags.alloc(n * 4));
-        HIP_TRY(d_nrows.alloc(n));
-        HIP_TRY(d_branch.alloc(n * K * 2));
-        HIP_TRY(d_score.alloc(n * K * 4));
-        HIP_TRY(d_lwr.alloc(n * K * 8));
-        HIP_TRY(d_oflags.alloc(n * 4));
-        if (nbytes) HIP_TRY(hipMemcpyAsync(d_ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-        rc = rk_pack_reads_device(db, n, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), wpr, d_packed.as<uint32_t>(),
-                                  d_lens.as<uint32_t>(), d_flags.as<uint32_t>(), s);
-        if (rc) return rc;
-        rk_result dres{d_nrows.as<uint8_t>(), d_branch.as<uint16_t>(), d_score.as<float>(), d_lwr.as<double>(), d_oflags.as<uint32_t>()};
-        rc = rk_place_packed_device(db, p, n, d_packed.as<uint32_t>(), wpr, d_lens.as<uint32_t>(), 0, d_flags.as<uint32_t>(),
-                                    d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), &dres, s);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out->n_rows + r0, d_nrows.p, n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->branch + r0 * K, d_branch.p, n * K * 2, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->score + r0 * K, d_score.p, n * K * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->lwr + r0 * K, d_lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->flags + r0, d_oflags.p, n * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        rk_workspace &w = db->ws[chunk_no & 1];
+        hipStream_t s = w.stream;
+        // the workspace was last used two chunks ago: its downloads must have landed before it is overwritten
+        hipError_t he = hipStreamSynchronize(s);
+        if (he != hipSuccess) { status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)); break; }
+        w.host_off.resize(n + 1);
+        for (uint64_t i = 0; i <= n; i++) w.host_off[i] = seq_off[r0 + i] - seq_off[r0];
+#define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
+#define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
+        WS_TRY(w.ascii.reserve(nbytes));
+        WS_TRY(w.off.reserve((n + 1) * 8));
+        WS_TRY(w.packed.reserve(n * wpr * 4));
+        WS_TRY(w.lens.reserve(n * 4));
+        WS_TRY(w.flags.reserve(n * 4));
+        WS_TRY(w.nrows.reserve(n));
+        WS_TRY(w.branch.reserve(n * K * 2));
+        WS_TRY(w.score.reserve(n * K * 4));
+        WS_TRY(w.lwr.reserve(n * K * 8));
+        WS_TRY(w.oflags.reserve(n * 4));
+        if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
+        WS_HIP(hipMemcpyAsync(w.off.p, w.host_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        WS_TRY(rk_pack_reads_device(db, n, w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), wpr, w.packed.as<uint32_t>(),
+                                    w.lens.as<uint32_t>(), w.flags.as<uint32_t>(), s));
+        {
+            rk_result dres{w.nrows.as<uint8_t>(), w.branch.as<uint16_t>(), w.score.as<float>(), w.lwr.as<double>(), w.oflags.as<uint32_t>()};
+            WS_TRY(rk_place_packed_device(db, p, n, w.packed.as<uint32_t>(), wpr, w.lens.as<uint32_t>(), 0, w.flags.as<uint32_t>(),
+                                          w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), &dres, s));
+        }
+        WS_HIP(hipMemcpyAsync(out->n_rows + r0, w.nrows.p, n, hipMemcpyDeviceToHost, s));
+        WS_HIP(hipMemcpyAsync(out->branch + r0 * K, w.branch.p, n * K * 2, hipMemcpyDeviceToHost, s));
+        WS_HIP(hipMemcpyAsync(out->score + r0 * K, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
+        WS_HIP(hipMemcpyAsync(out->lwr + r0 * K, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
+        WS_HIP(hipMemcpyAsync(out->flags + r0, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
+#undef WS_TRY
+#undef WS_HIP
         r0 = r1;
+        chunk_no++;
     }
+done:
+    for (rk_workspace &w : db->ws)
+        if (w.stream) {
+            hipError_t he = hipStreamSynchronize(w.stream);
+            if (he != hipSuccess && status == RK_OK) status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he));
+        }
+    if (status != RK_OK) return status;
     for (uint64_t r = 0; r < n_reads; r++) {
         uint32_t f = out->flags[r];
         ct.reads++;
