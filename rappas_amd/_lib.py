@@ -54,6 +54,8 @@ EXPORTS = {
     "rk_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(rk_db_info)]),
     "rk_place_batch": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.POINTER(rk_result), C.POINTER(rk_counters)]),
+    "rk_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "rk_host_free": (None, [C.c_void_p]),
     "rk_packed_words": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "rk_pack_reads_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -483,6 +483,20 @@ extern "C" int rk_db_get_info(const rk_db *db, rk_db_info *info) {
     return RK_OK;
 }
 
+extern "C" void *rk_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)fail(e == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "rk_host_alloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void rk_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" uint32_t rk_packed_words(const rk_db *db, uint32_t max_len) {
     if (!db) return 0;
     uint64_t bits = (uint64_t)max_len * db->info.bits_per_symbol;
