@@ -159,3 +159,39 @@ def pack_reads_numpy(alphabet, seq, off, words_per_read=None):
         for w in range(wpr):
             out[r, w] = (acc >> (32 * w)) & 0xFFFFFFFF
     return out, lens.astype(np.uint32)
+
+
+def make_newick(n_nodes, seed=7):
+    """Random tree with exactly `n_nodes` nodes for the host-side tools and their tests: binary and rooted when n_nodes is
+    odd, an unrooted top level (three sons) when it is even.  Leaves are named t<id>, internal nodes n<id> (ids = order of
+    appearance, as the reference's NewickReader numbers them), branch lengths are short decimals."""
+    if n_nodes < 3:
+        raise ValueError("need at least 3 nodes")
+    rng = np.random.default_rng(seed)
+    counter = [0]
+
+    def split_odd(total, parts):
+        # `parts` odd sizes summing to `total`
+        left = total - parts
+        out = [1] * parts
+        for _ in range(left // 2):
+            out[int(rng.integers(parts))] += 2
+        return out
+
+    def build(count, top):
+        me = counter[0]
+        counter[0] += 1
+        bl = "" if top else ":%.4f" % (0.001 + float(rng.random()) * 0.5)
+        if count == 1:
+            return f"t{me}{bl}"
+        sons = 3 if (count - 1) % 2 else 2
+        sizes = split_odd(count - 1, sons)
+        return "(" + ",".join(build(c, False) for c in sizes) + f")n{me}{bl}"
+
+    import sys
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old, 4 * n_nodes + 100))
+    try:
+        return build(n_nodes, True) + ";"
+    finally:
+        sys.setrecursionlimit(old)

@@ -1,0 +1,61 @@
+"""`python -m rappas_amd.tools.place`: FASTA queries + a --jsondb dump -> .jplace, through the GPU engine.
+
+The reference's `-p p` phase for one query file (src/main_v2/Main_PLACEMENT_v07.java:150-320) with the database taken
+from the JSON dump `--jsondb` writes (src/main_v2/SessionNext_v2.java:214-270) instead of the Java-serialized .union.
+Only the placement itself runs on the GPU; ingest and the jplace writer are rappas_amd/hostio.py.
+"""
+import argparse
+import sys
+
+import numpy as np
+
+from .. import hostio
+from ..placement import PhyloKmerDB, PlacementProcess
+
+
+def place_file(db_text, fasta_text, keep_at_most=7, keep_factor=0.01, amb="mean", ns_bound=float("-inf"), guppy=False,
+               call_string="", device=0):
+    d = hostio.load_jsondb(db_text)
+    tree = d["tree"]
+    db = PhyloKmerDB(d["alphabet"], d["k"], d["n_branches"], d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"],
+                     d["branch_ids"], d["scores"], device=device)
+    try:
+        unique, names = hostio.dedup_reads(hostio.read_fasta(fasta_text))
+        seq, off = hostio.pack_batch([s for _, s in unique])
+        res = PlacementProcess(db, ns_bound).processQueries(
+            seq, off, keepAtMost=keep_at_most, keepFactor=keep_factor, treatAmbiguities=(amb != "skip"),
+            treatAmbiguitiesWithMax=(amb == "max"))
+    finally:
+        db.close()
+    pl = hostio.jplace_placements(tree, names, res.n_rows, res.branch, res.score, res.lwr, guppy)
+    return hostio.jplace_document(tree, pl, call_string, guppy), res
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="rappas_amd.tools.place", description=__doc__.splitlines()[0])
+    ap.add_argument("--jsondb", required=True, help="database dump written by the reference's --jsondb")
+    ap.add_argument("--fasta", required=True, help="query reads (-q)")
+    ap.add_argument("--out", required=True, help="output .jplace")
+    ap.add_argument("--keep-at-most", type=int, default=7)
+    ap.add_argument("--keep-factor", type=float, default=0.01)
+    ap.add_argument("--amb", choices=["mean", "max", "skip"], default="mean", help="--ambwithmax / --noamb")
+    ap.add_argument("--nsbound", type=float, default=float("-inf"))
+    ap.add_argument("--guppy-compat", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    with open(a.jsondb, "rb") as f:
+        db_text = f.read()
+    with open(a.fasta, "rb") as f:
+        fasta_text = f.read()
+    call = "".join(" " + x for x in (argv if argv is not None else sys.argv[1:]))
+    doc, res = place_file(db_text, fasta_text, a.keep_at_most, a.keep_factor, a.amb, a.nsbound, a.guppy_compat, call,
+                          a.device)
+    with open(a.out, "w") as f:
+        f.write(doc)
+    placed = int(np.count_nonzero(res.n_rows))
+    print(f"{len(res.n_rows)} unique reads, {placed} placed -> {a.out}", file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

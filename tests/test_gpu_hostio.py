@@ -1,0 +1,63 @@
+"""End to end through the host-side rows (FASTA -> dedup -> GPU placement -> jplace) against the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rappas_amd import hostio, synth
+from rappas_amd.tools import place as place_tool
+
+pytestmark = pytest.mark.gpu
+
+
+def _fasta(db, n, length, seed):
+    seq, off = synth.make_reads(db.alphabet, n, length, seed=seed, amb_rate=0.002)
+    reads = [bytes(seq[int(off[i]):int(off[i + 1])]).decode() for i in range(n)]
+    lines = []
+    for i, r in enumerate(reads):
+        lines.append(f">read{i} sample=x/{i}")
+        lines += [r[j:j + 60] for j in range(0, len(r), 60)]
+        if i % 10 == 3:  # a duplicate with a gap inserted and another header
+            lines.append(f">dup{i} of read{i}")
+            lines.append(r[:7] + "-" + r[7:])
+    return "\n".join(lines) + "\n", reads
+
+
+@pytest.mark.parametrize("n_nodes,amb", [(101, "mean"), (64, "max")])
+def test_fasta_to_jplace_matches_oracle(tmp_path, n_nodes, amb):
+    db = synth.make_db(4, 6, n_nodes, 3000, 20000, seed=11)
+    nwk = synth.make_newick(n_nodes, seed=5)
+    fasta, reads = _fasta(db, 200, 120, seed=9)
+    (tmp_path / "db.json").write_text(hostio.dump_jsondb(db, nwk))
+    (tmp_path / "q.fasta").write_text(fasta)
+    out = tmp_path / "q.jplace"
+    assert place_tool.main(["--jsondb", str(tmp_path / "db.json"), "--fasta", str(tmp_path / "q.fasta"), "--out", str(out),
+                            "--amb", amb]) == 0
+    js = json.loads(out.read_text())
+    tree = hostio.parse_newick(nwk)
+    assert js["tree"] == tree.jplace_newick() and js["version"] == 3
+
+    # expectation from the oracle on the unique reads
+    uniq, names = hostio.dedup_reads(hostio.read_fasta(fasta))
+    assert [s for _, s in uniq] == reads  # the gapped duplicates collapse onto their originals
+    seq, off = hostio.pack_batch(reads)
+    odb = O.OracleDB.from_synth(db)
+    ref = odb.place(seq, off, amb_mode=O.AMB_MEAN if amb == "mean" else O.AMB_MAX)
+    want = [i for i in range(len(reads)) if ref["n_rows"][i]]
+    assert len(js["placements"]) == len(want) > 150
+    ties = 0
+    for p, i in zip(js["placements"], want):
+        assert p["nm"] == [[nm, 1] for nm in names[i]]
+        n = int(ref["n_rows"][i])
+        assert len(p["p"]) == n
+        for j, row in enumerate(p["p"]):
+            assert np.float32(row[1]) == ref["score"][i, j]  # Float.toString round-trips
+            assert row[2] == pytest.approx(ref["lwr"][i, j], rel=1e-9) and row[4] == 0.0
+            if ref["flags"][i] & O.RO_FLAG_TIE:
+                ties += 1
+                continue
+            node = tree.nodes[int(ref["branch"][i, j])]
+            assert row[0] == node.jplace_edge
+            assert np.float32(row[3]) == node.bl / np.float32(2)
+    assert names[3] == ["read3 sample=x/3", "dup3"]
