@@ -13,13 +13,17 @@ typedef unsigned int u32;
 constexpr int DESC_LEN_BITS = 24;
 constexpr u32 DESC_LEN_MASK = (1u << DESC_LEN_BITS) - 1;
 
-// Row image in the blob: len entries of 8 bytes {u32 branch id (16 bits used), f32 score}, 8-byte aligned.
+// Row image in the blob: len entries of 8 bytes {u32 slot offset, f32 score}, 8-byte aligned.
 // One dwordx2 load per lane fetches an entry; chunk c of a row simply starts G entries further.
+// `branch` holds the BYTE offset of the branch's word in the per-read score vector, (branch id + 1) * 4: word 0 of
+// the vector is a scratch slot, so all-zero padding entries (and whatever an out-of-range buffer load returns: zeros)
+// update the scratch word and need no test in the accumulate loop.  (Large-tree images keep raw u16 ids, see soa.)
 // (Algorithmic size of an entry is 6 bytes -- u16 + f32 -- that is what the roofline accounting uses.)
 struct __attribute__((aligned(8))) Entry {
     u32 branch;
     float score;
 };
+constexpr u32 ROWS_FIT32_LIMIT = 0x7FFF0000u;  // blobs below this use 32-bit offsets (bit 31 of a chunk item is a flag)
 constexpr u32 ROW_UNIT = 8;  // entries per 64-byte line; rows are line-aligned and padded to whole lines
 
 // k-mer -> row lookup flavours (template parameter of the kernels)
@@ -35,6 +39,7 @@ struct DbView {
     const uint4 *slots;  // [hash_mask+1] {key+1 lo, key+1 hi, desc lo, desc hi} (RK_TABLE_HASH) or nullptr
     u64 hash_mask;
     const unsigned char *rows;
+    u64 rows_bytes;
     u32 k, bits, n_branches, alphabet;
     float T, P;
     u32 convert_uo;

@@ -297,7 +297,8 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     const uint64_t blob_bytes = blob_units * 64;
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
     std::vector<Entry> &blob = img.blob;
-    try { blob.assign(blob_bytes / 8, indexed ? Entry{0xFFFFFFFFu, 0.0f} : Entry{0xFFFFu, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
+    // padding / reserved line 0: raw-id images (large trees) skip on 0xFFFF, slot-offset images update scratch slot 0
+    try { blob.assign(blob_bytes / 8, indexed ? Entry{0xFFFFFFFFu, 0.0f} : Entry{0u, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
     {
         std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
         for (uint64_t r = 0; r < n_keys; r++) {
@@ -312,7 +313,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
                 if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
                 stamp[x] = (uint32_t)r;
                 if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
-                ep[i].branch = x;
+                ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
                 ep[i].score = v;
             }
             if (indexed) {
@@ -470,6 +471,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     db->view.slots = mode == RK_TABLE_HASH ? (const uint4 *)db->d_table : nullptr;
     db->view.hash_mask = hash_mask;
     db->view.rows = (const unsigned char *)db->d_rows;
+    db->view.rows_bytes = db->info.rows_bytes;
     db->view.k = d->k; db->view.bits = bits; db->view.n_branches = d->n_branches; db->view.alphabet = d->alphabet;
     db->view.T = d->thr_log10; db->view.P = d->thr; db->view.convert_uo = d->convert_uo;
     db->view.soa = indexed ? 1u : 0u;
@@ -588,8 +590,8 @@ static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &a
 
 template <int G, int BITS, int TM>
 static int launch_w(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
-    // 32-bit row offsets whenever the row blob is < 4 GiB
-    return db->info.rows_bytes < (1ull << 32) ? launch_variant<G, BITS, TM, false>(db, g, a, s)
+    // 32-bit row offsets whenever the row blob is < 2 GiB (bit 31 of a chunk item is a flag)
+    return db->info.rows_bytes < ROWS_FIT32_LIMIT ? launch_variant<G, BITS, TM, false>(db, g, a, s)
                                               : launch_variant<G, BITS, TM, true>(db, g, a, s);
 }
 template <int G, int BITS>
@@ -647,7 +649,7 @@ static int launch_wg_v(const rk_db *db, const WgGeometry &g, PlaceArgs a, hipStr
     uint64_t blocks = (uint64_t)db->cu_count * g.wgs_per_cu;
     if (blocks > a.n_reads) blocks = a.n_reads;
     if (!blocks) return RK_OK;
-    if (db->info.rows_bytes < (1ull << 32)) {
+    if (db->info.rows_bytes < ROWS_FIT32_LIMIT) {
         auto kern = place_wg_kernel<BITS, TM, false, RK_RING>;
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * g.nw), g.lds, stream, a);
@@ -728,14 +730,14 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         if (choose_wg_geometry(db, wg) != RK_OK) return "";
         snprintf(buf, sizeof(buf), "place_wg_kernel<BITS=%u,%s,%s,U=%d> waves/WG=%u lds/WG=%zuB rows/batch=%u WGs/CU=%u",
                  db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_HASH ? "HASH" : "DIRECT8",
-                 db->info.rows_bytes < (1ull << 32) ? "OFF32" : "OFF64", RK_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu);
+                 db->info.rows_bytes < ROWS_FIT32_LIMIT ? "OFF32" : "OFF64", RK_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu);
         m->kernel_name = buf;
         return m->kernel_name.c_str();
     }
     if (choose_geometry(db, 7, g) != RK_OK) return "";
     snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
              g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
-             db->info.rows_bytes < (1ull << 32) ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
+             db->info.rows_bytes < ROWS_FIT32_LIMIT ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();
 }

@@ -89,7 +89,7 @@ __device__ __forceinline__ void load_entry(const DbView &db, u64 desc, u32 e, u3
         sc = ((const float *)(base + 2 * (size_t)len))[e];
     } else {
         const Entry en = ((const Entry *)base)[e];
-        br = en.branch;
+        br = en.branch ? (en.branch >> 2) - 1u : 0xFFFFu;  // slot offset -> branch id; all-zero padding -> "skip"
         sc = en.score;
     }
 }
@@ -211,7 +211,7 @@ struct Cursor {
 };
 
 // Branch-free on purpose: every lane always issues its row load (lanes without an entry read the reserved entry
-// at blob offset 0, whose branch id 0xFFFF means "skip"), and nothing selects on a loaded value here, so the
+// at blob offset 0, which updates the scratch slot), and nothing selects on a loaded value here, so the
 // compiler counts outstanding loads exactly (s_waitcnt vmcnt(N)) and the register ring keeps U chunks in flight
 // per lane.  list[cnt] must be a zero descriptor (sentinel).  SOA: rows are u16 branch[len] | f32 score[len].
 template <int G, bool WIDE, bool SOA>
@@ -234,7 +234,8 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
     if (SOA) {
         const off_t bo = ok ? (off_t)(c.cur + 2 * li) : (off_t)0;
         const off_t so = ok ? (off_t)(c.scur + 4 * li) : (off_t)0;
-        br = *(const unsigned short *)(rows + bo);
+        const u32 b16 = *(const unsigned short *)(rows + bo);
+        br = (b16 == 0xFFFFu) ? 0u : (b16 + 1u) * 4u;  // raw id -> slot offset (0xFFFF = padding / reserved line 0)
         sc = *(const float *)(rows + so);
         c.cur += 2 * G;
         c.scur += 4 * G;
@@ -264,6 +265,20 @@ __device__ __forceinline__ void apply_entry(u32 *S, u32 nb, u32 br, float sc, fl
     const float nw = base + d;
     S[idx] = __float_as_uint(nw);
 }
+// Same update for the slot layout of the packed / ASCII kernels: word 0 of S is the scratch slot, branch x lives in
+// word x + 1, and `sb` is the word's byte offset as the row entries carry it (0 for padding).
+__device__ __forceinline__ void apply_slot(u32 *S, u32 sb, float sc, float QT, float T) {
+    if (RK_ABLATE & 8) {
+        asm volatile("" ::"v"(sb), "v"(sc));
+        return;
+    }
+    u32 *p = (u32 *)((unsigned char *)S + sb);
+    const u32 old = *p;
+    const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+    const float d = sc - T;
+    const float nw = base + d;
+    *p = __float_as_uint(nw);
+}
 __device__ __forceinline__ void apply_entry_masked(u32 *S, u32 br, float sc, float QT, float T) {
     u32 old = S[br];
     float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
@@ -285,13 +300,13 @@ __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list,
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_entry(S, nb, br[u], sc[u], QT, T);
+            apply_slot(S, br[u], sc[u], QT, T);
             cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u]);
         }
         if (!__any(c.h < cnt)) break;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) apply_entry(S, nb, br[u], sc[u], QT, T);
+    for (int u = 0; u < U; u++) apply_slot(S, br[u], sc[u], QT, T);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,12 +362,60 @@ __device__ __forceinline__ void accumulate_chunks(u32 *S, u32 nb, const typename
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_entry(S, nb, br[u], sc[u], QT, T);
+            apply_slot(S, br[u], sc[u], QT, T);
             chunk_issue<G, WIDE>(it[u], s0 + U + u < cnt, li, li8, rows, br[u], sc[u]);
             it[u] = items[s0 + 2 * U + u];
         }
         s0 += U;
         if (!__any(s0 < cnt)) break;  // what is left in the ring belongs to steps >= cnt of every group: all skips
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate, G == 16 with 32-bit offsets (the usual geometry): a chunk is one or two 64-byte lines and its item is
+//   byte offset of the first line | ITEM_ONE_LINE (bit 31) when the second line does not belong to the row.
+// Rows are read through a raw buffer descriptor over the blob: lanes 0-7 clear bit 31, lanes 8-15 keep it, so
+// for a one-line chunk their offset falls outside the buffer -- the load returns zeros without touching memory and
+// the update goes to the scratch slot.  List slots past a group's own count hold ITEM_FILLER (out of range for
+// both halves), so a step is: item & lane mask, + lane offset, one buffer load, one LDS read-modify-write --
+// no bounds test, no count test, no 64-bit address arithmetic.  `wcnt` = the largest count among the wave's groups.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 ITEM_ONE_LINE = 0x80000000u;
+constexpr u32 ITEM_FILLER = 0xFFFFFF00u;
+typedef u32 v2u32 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_resource(const DbView &db) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)db.rows, (short)0, (int)(u32)db.rows_bytes, 0x00020000);
+}
+
+template <int U>
+__device__ __forceinline__ void accumulate_chunks16(u32 *S, const u32 *items, int wcnt, u32 li,
+                                                    __amdgpu_buffer_rsrc_t rs, float QT, float T) {
+    const u32 amask = (li & 8u) ? 0xFFFFFFFFu : ~ITEM_ONE_LINE;
+    const u32 li8 = li * 8;
+    u32 sb[U], it[U];
+    float sc[U];
+    auto issue = [&](u32 item, u32 &b, float &v) {
+        u32 off = (item & amask) + li8;
+        if (RK_ABLATE & 16) off = li8;
+        const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+        b = e.x;
+        v = __uint_as_float(e.y);
+    };
+#pragma unroll
+    for (int u = 0; u < U; u++) issue(items[u], sb[u], sc[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) it[u] = items[U + u];
+    int s0 = 0;
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            apply_slot(S, sb[u], sc[u], QT, T);
+            issue(it[u], sb[u], sc[u]);
+            it[u] = items[s0 + 2 * U + u];
+        }
+        s0 += U;
+        if (s0 >= wcnt) break;  // what is left in the ring are fillers
     }
 }
 
@@ -435,7 +498,9 @@ __device__ __forceinline__ int rank_candidates(const u64 *list, int c, u64 *win,
 // `list` has `cap` u64 slots; the last 16 are the winners' scratch.  S must be 16-byte aligned with s_stride % 4 == 0
 // (slots in [nb, s_stride) are scratch).  Returns numBest (group-uniform).
 template <int G>
-__device__ __forceinline__ int select_topk_scan(u32 *S, u32 nb, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+__device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+    // slot layout: S[0] is the scratch word (the caller has set it to UNTOUCHED), branch x is S[x + 1], ns = n_branches + 1
+    const u32 nb = ns;
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     u64 *win = list + (cap - 16);
     const int capc = cap - 16;
@@ -444,7 +509,7 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 nb, u32 li, u32 gi, 
     const u32 n4 = (nb + 3) / 4;
     // ---- pass 1 ----
     float mo = -INFINITY;
-    u32 mi = 0xFFFFu;
+    u32 mi = 0xFFFFFFFFu;
     for (u32 q = li; q < n4; q += G) {
         const uint4 v4 = S4[q];
         const u32 i = 4 * q;
@@ -456,7 +521,7 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 nb, u32 li, u32 gi, 
             mi = gt ? i + e : mi;
         }
     }
-    const u64 km = (mi != 0xFFFFu) ? make_key(__float_as_uint(mo), mi) : 0ull;
+    const u64 km = (mi != 0xFFFFFFFFu) ? make_key(__float_as_uint(mo), mi - 1u) : 0ull;
     // ---- tau = K-th largest lane maximum (0 if fewer than K lanes saw anything) ----
     const int rank = RankAbove<G, G - 1>::run(km, li);
     u64 tau = group_max<G>((rank == K - 1) ? km : 0ull);
@@ -473,7 +538,7 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 nb, u32 li, u32 gi, 
         bool any = false;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            key[e] = (raw[e] != S_UNTOUCHED && i + e < nb) ? make_key(raw[e], i + e) : 0ull;
+            key[e] = (raw[e] != S_UNTOUCHED && i + e < nb) ? make_key(raw[e], i + e - 1u) : 0ull;
             any = any || (key[e] != 0 && key[e] >= tau);
         }
         if (((__ballot(any) >> (gi * G)) & gmask) == 0) continue;  // group-uniform: no candidate in these 4G entries
@@ -508,14 +573,19 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 nb, u32 li, u32 gi, 
 // still hide a better entry (it dropped something >= the K-th winner) -- rare (a lane would need >= 4 of the top K);
 // then the exact two-pass scan above runs instead.  S is reset with plain 16-byte stores afterwards.
 template <int G>
-__device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+__device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+    // slot layout: the scratch word S[0] leaves the competition, then the scan runs over ns = n_branches + 1 slots and
+    // slot i stands for branch i - 1
+    if (li == 0) S[0] = S_UNTOUCHED;
+    wave_lds_fence();
+    const u32 nb = n_branches + 1;
     if (K > 8) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key);
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     const uint4 *S4 = (const uint4 *)S;
     uint4 *S4w = (uint4 *)S;
     const u32 n4 = (nb + 3) / 4;
     float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
-    u32 i0 = 0xFFFFu, i1 = 0xFFFFu, i2 = 0xFFFFu;
+    u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
     // sorted insertion into the lane's top three; strict '>' keeps the smaller branch id ahead among equal scores and
     // is false for the NaN marker of untouched branches
     auto feed = [&](float v, u32 idx, bool in) {
@@ -550,9 +620,9 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 nb, u32 li, u32 gi, int K
         feed(__uint_as_float(v4.z), i + 2, i + 2 < nb);
         feed(__uint_as_float(v4.w), i + 3, i + 3 < nb);
     }
-    u64 k0 = (i0 != 0xFFFFu) ? make_key(__float_as_uint(s0), i0) : 0ull;
-    u64 k1 = (i1 != 0xFFFFu) ? make_key(__float_as_uint(s1), i1) : 0ull;
-    u64 k2 = (i2 != 0xFFFFu) ? make_key(__float_as_uint(s2), i2) : 0ull;
+    u64 k0 = (i0 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s0), i0 - 1u) : 0ull;
+    u64 k1 = (i1 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s1), i1 - 1u) : 0ull;
+    u64 k2 = (i2 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s2), i2 - 1u) : 0ull;
     win_key = 0;
     int num = 0;
     u64 last = 0;
@@ -651,6 +721,8 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     const u32 k = a.db.k;
     const float T = a.db.T;
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    constexpr bool FAST16 = (G == 16 && !WIDE);  // buffer-addressed one/two-line chunks (accumulate_chunks16)
+    const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     // chunk items the list can take (3U slots of slack for the read-ahead of accumulate_chunks)
     const int cap_items = (int)(a.list_cap * (sizeof(u64) / sizeof(item_t))) - 3 * U - 2;
     const int cap_rows = (int)a.list_cap - 1;  // row descriptors (fallback path), one slot for the sentinel
@@ -693,6 +765,21 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         u32 pos = 0;
         int cnt = 0;  // chunk items waiting in the list
         auto flush = [&]() {
+            if (FAST16) {
+                // the longest list of the wave's four groups sets the step count; shorter lists are padded with fillers
+                int wcnt = __builtin_amdgcn_readlane(cnt, 0);
+                wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 16));
+                wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 32));
+                wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 48));
+                for (int i = cnt + (int)li; i < wcnt + 2 * U; i += G) ((u32 *)items)[i] = ITEM_FILLER;
+                wave_lds_fence();
+                RK_STAMP(3);
+                if (!(RK_ABLATE & 1)) accumulate_chunks16<U>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
+                wave_lds_fence();
+                RK_STAMP(4);
+                cnt = 0;
+                return;
+            }
             wave_lds_fence();
             RK_STAMP(3);
             if (!(RK_ABLATE & 1)) accumulate_chunks<G, U, WIDE>(S, nb, items, cnt, li, a.db.rows, QT, T);
@@ -805,6 +892,15 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     const u64 off8 = desc[u] >> DESC_LEN_BITS;
                     const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;
                     const int base = cnt + (int)excl[u];
+                    if (FAST16) {
+                        const u32 rb = (u32)off8 * 8u;  // byte offset of the row (64-byte aligned)
+                        u32 *it32 = (u32 *)items;
+                        if (nch[u] > 0) it32[base] = rb | (lenp <= 8u ? ITEM_ONE_LINE : 0u);
+                        if (nch[u] > 1) it32[base + 1] = (rb + 128u) | (lenp <= 24u ? ITEM_ONE_LINE : 0u);
+                        for (u32 c = 2; __any(c < nch[u]); c++)
+                            if (c < nch[u]) it32[base + (int)c] = (rb + c * 128u) | (lenp - c * 16u <= 8u ? ITEM_ONE_LINE : 0u);
+                        continue;
+                    }
                     // most rows are 1-2 chunks: those are written without a wave vote, the rest in a voted loop
                     if (nch[u] > 0) items[base] = make_item<G, WIDE>(off8, lenp < (u32)G ? lenp : (u32)G);
                     if (nch[u] > 1) items[base + 1] = make_item<G, WIDE>(off8 + G, lenp - G < (u32)G ? lenp - G : (u32)G);
@@ -825,7 +921,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         // ---- select + weigh + store (also resets S) ----
         u64 win_key;
         int numBest = 0;
-        if (RK_ABLATE & 2) { win_key = list[0]; for (u32 i = li; i < nb; i += G) S[i] = S_UNTOUCHED; }
+        if (RK_ABLATE & 2) { win_key = list[0]; for (u32 i = li; i <= nb; i += G) S[i] = S_UNTOUCHED; }
         else numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
         wave_lds_fence();
         RK_STAMP(5);  // select
@@ -1154,7 +1250,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                     const u32 x = xb[w];
                     const u32 c = Camb[x];
                     if (c != 0) {
-                        const u32 old = S[x];
+                        const u32 old = S[x + 1];  // slot layout: branch x is word x + 1
                         const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
                         float nw;
                         if (m.amb_mode == RK_AMB_MEAN) {
@@ -1167,7 +1263,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                             const float dd = Samb[x] - T;
                             nw = base + dd;
                         }
-                        S[x] = __float_as_uint(nw);
+                        S[x + 1] = __float_as_uint(nw);
                         Camb[x] = 0;
                         Samb[x] = 0.0f;
                     }
@@ -1217,7 +1313,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 if (x >= chunk) continue;  // also skips pad entries (0xFFFF >= any chunk window)
                 u32 c = Camb[x];
                 if (c != 0) {
-                    u32 old = S[xb];
+                    u32 old = S[xb + 1];
                     float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
                     float nw;
                     if (m.amb_mode == RK_AMB_MEAN) {
@@ -1230,7 +1326,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                         float d = Samb[x] - T;  // :1230
                         nw = base + d;
                     }
-                    S[xb] = __float_as_uint(nw);
+                    S[xb + 1] = __float_as_uint(nw);
                     Camb[x] = 0;
                     Samb[x] = 0.0f;
                 }
