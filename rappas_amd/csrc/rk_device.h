@@ -23,15 +23,16 @@ struct __attribute__((aligned(8))) Entry {
     u32 branch;
     float score;
 };
-constexpr u32 ROWS_FIT32_LIMIT = 0x7FFF0000u;  // blobs below this use 32-bit offsets (bit 31 of a chunk item is a flag)
-constexpr u32 ROW_UNIT = 8;  // entries per 64-byte line; rows are line-aligned and padded to whole lines
+constexpr u32 ROWS_FIT32_LIMIT = 0xFFFF0000u;  // blobs below this use 32-bit offsets (ITEM_FILLER must stay outside the buffer)
+constexpr u32 ROW_UNIT = 16;  // entries per 128-byte unit; rows are unit-aligned and padded to whole units
 
 // k-mer -> row lookup flavours (template parameter of the kernels)
 constexpr int TM_HASH = 0, TM_DIRECT8 = 1, TM_COMPACT = 2;
 constexpr u32 COMPACT_KMERS = 12;  // k-mers per 16-byte block of the compact direct table
 
-// Untouched marker for the per-read LDS score vector (a NaN pattern no finite sum can produce).
-constexpr u32 S_UNTOUCHED = 0xFFFFFFFFu;
+// Untouched marker of the per-read LDS score vector: -inf.  No finite sum of finite scores produces it, it loses every
+// '>' comparison of the select phase, and max(marker, Q*T) seeds a first touch.
+constexpr u32 S_UNTOUCHED = 0xFF800000u;
 
 struct DbView {
     const u64 *direct;   // [sigma^k] row descriptors (RK_TABLE_DIRECT8) or nullptr
@@ -43,6 +44,7 @@ struct DbView {
     u32 k, bits, n_branches, alphabet;
     float T, P;
     u32 convert_uo;
+    u32 mono;  // every score >= T (all increments >= 0): first touch of a branch can be a max with the -inf marker
     u32 soa;  // large-tree (indexed) images: a row is u16 branch[len] followed by f32 score[len] (6 bytes per entry)
 };
 

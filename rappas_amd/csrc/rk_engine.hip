@@ -190,6 +190,7 @@ extern "C" void rk_db_destroy(rk_db *db) {
 struct DbImage {
     uint32_t mode = 0, bits = 0, max_len = 0;
     bool indexed = false;
+    bool mono = true;  // every score >= thr_log10 (true of every database RAPPAS builds: words below the threshold are not stored)
     uint64_t n_keys = 0, n_entries = 0, blob_bytes = 0, slots = 0, hash_mask = 0;
     std::vector<Entry> blob;
     std::vector<uint64_t> table;
@@ -260,8 +261,8 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
         if (order[i].first == order[i - 1].first)
             return fail(RK_ERR_INVALID, "rk_db_create: duplicate k-mer code at key %llu", (unsigned long long)order[i].second);
 
-    // ---- row blob: every row starts on a 64-byte line and is padded to whole lines (8 entries) with "skip"
-    //      entries, so a row of n entries costs exactly ceil(n/8) line requests; line 0 is reserved (all skip) ----
+    // ---- row blob: every row starts on a 128-byte unit and is padded to whole units (16 entries) with zero entries,
+    //      so a row of n entries costs exactly ceil(n/16) aligned 128-byte requests; unit 0 is reserved (all padding) ----
     // Large trees (n_branches > RK_WG_MIN_BRANCHES): the score vector of one read fills most of a CU's LDS, so a whole
     // workgroup shares it and every wave owns a branch range (place_wg_kernel).  Rows are then sorted by branch id
     // and preceded by one 64-byte INDEX line: u16 split[i-1] = number of entries with branch < floor(i * n_branches / 32),
@@ -270,7 +271,10 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES;
     img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
-    uint64_t blob_units = 1;             // 64-byte units
+    // slot-offset images: 128-byte units (ROW_UNIT = 16 entries), so a chunk of 16 entries is ONE aligned 128-byte request;
+    // raw-id (indexed) images: 64-byte units
+    const uint64_t unit_bytes = indexed ? 64 : ROW_UNIT * 8;
+    uint64_t blob_units = 1;  // unit 0 is reserved (padding pattern)
     uint32_t max_len = 0;
     uint64_t max_units = 0;
     for (uint64_t i = 0; i < n_keys; i++) {
@@ -282,7 +286,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
         if (len > d->n_branches)
             return fail(RK_ERR_INVALID, "rk_db_create: row %llu has %llu entries (> n_branches)", (unsigned long long)r, (unsigned long long)len);
         if (len > max_len) max_len = (uint32_t)len;
-        uint64_t units = (len + ROW_UNIT - 1) / ROW_UNIT;  // 64-byte lines of 8 {branch, score} entries
+        uint64_t units = (len + ROW_UNIT - 1) / ROW_UNIT;  // 128-byte units of 16 {slot offset, score} entries
         uint64_t lenp = units * ROW_UNIT;
         if (indexed) {
             // [index line][u16 branch[lenp]][f32 score[lenp]], lenp a multiple of 32 so that the row is whole lines
@@ -291,10 +295,10 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
             units = lenp * 6 / 64;
         }
         if (units > max_units) max_units = units;
-        desc[r] = ((blob_units * 8) << DESC_LEN_BITS) | lenp;
+        desc[r] = ((blob_units * (unit_bytes / 8)) << DESC_LEN_BITS) | lenp;
         blob_units += units;
     }
-    const uint64_t blob_bytes = blob_units * 64;
+    const uint64_t blob_bytes = blob_units * unit_bytes;
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create: row blob exceeds 8 TiB");
     std::vector<Entry> &blob = img.blob;
     // padding / reserved line 0: raw-id images (large trees) skip on 0xFFFF, slot-offset images update scratch slot 0
@@ -313,6 +317,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
                 if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
                 stamp[x] = (uint32_t)r;
                 if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
+                if (!(v >= d->thr_log10)) img.mono = false;
                 ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
                 ep[i].score = v;
             }
@@ -340,8 +345,8 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     // ---- table ----
     // DIRECT  : compact blocks, 16 bytes per 12 consecutive k-mers {u32 first row unit, 12 x u8 units per row}: 1.33 bytes
     //           per k-mer (1.4 MiB at k=10), small enough to live in the XCD L2s, one dwordx4 gather per probe; a row's
-    //           offset is the block base plus a byte prefix sum.  Needs rows of <= 255 units (2040 entries) and a blob
-    //           of < 2^32 units (256 GiB); otherwise DIRECT falls back to DIRECT8.
+    //           offset is the block base plus a byte prefix sum.  Needs rows of <= 255 units (4080 entries) and a blob
+    //           of < 2^32 units (512 GiB); otherwise DIRECT falls back to DIRECT8.
     // DIRECT8 : one 8-byte descriptor per k-mer.
     // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
     if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32) || indexed)) mode = RK_TABLE_DIRECT8;
@@ -475,6 +480,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     db->view.k = d->k; db->view.bits = bits; db->view.n_branches = d->n_branches; db->view.alphabet = d->alphabet;
     db->view.T = d->thr_log10; db->view.P = d->thr; db->view.convert_uo = d->convert_uo;
     db->view.soa = indexed ? 1u : 0u;
+    db->view.mono = img.mono ? 1u : 0u;
     *out = db;
     return RK_OK;
 }
@@ -590,7 +596,7 @@ static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &a
 
 template <int G, int BITS, int TM>
 static int launch_w(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
-    // 32-bit row offsets whenever the row blob is < 2 GiB (bit 31 of a chunk item is a flag)
+    // 32-bit row offsets whenever the row blob is < 4 GiB
     return db->info.rows_bytes < ROWS_FIT32_LIMIT ? launch_variant<G, BITS, TM, false>(db, g, a, s)
                                               : launch_variant<G, BITS, TM, true>(db, g, a, s);
 }
@@ -908,7 +914,7 @@ done:
 // diagnostic builds only (scripts/stamps.py)
 extern "C" int rk_debug_read_stamps(unsigned long long *out, int n_waves) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rk::rk_stamp_buf), (size_t)n_waves * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rk::rk_stamp_buf), (size_t)n_waves * 16 * sizeof(unsigned long long)));
     return RK_OK;
 }
 #endif

@@ -30,7 +30,7 @@ namespace rk {
 
 #ifdef RK_STAMPS
 // Diagnostic build only (scripts/stamps.py): per-wave cycle sums of the kernel phases. Never compiled into the product.
-__device__ unsigned long long rk_stamp_buf[4096 * 8];
+__device__ unsigned long long rk_stamp_buf[4096 * 16];
 __device__ __forceinline__ unsigned long long rk_now() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -39,8 +39,12 @@ __device__ __forceinline__ unsigned long long rk_now() {
     return t;
 }
 #define RK_STAMP(slot) do { unsigned long long n_ = rk_now(); st_[slot] += n_ - t_; t_ = n_; } while (0)
+#define RK_STAMP_PARAMS , unsigned long long *st_, unsigned long long &t_
+#define RK_STAMP_ARGS , st_, t_
 #else
 #define RK_STAMP(slot) do {} while (0)
+#define RK_STAMP_PARAMS
+#define RK_STAMP_ARGS
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -154,7 +158,7 @@ __device__ __forceinline__ RawSlot lookup_fetch(const DbView &db, u64 code) {
 template <int BITS, int TM>
 __device__ __forceinline__ u64 lookup_decode(const DbView &db, const RawSlot &r, u64 code) {
     if (TM == TM_COMPACT) {
-        // 16-byte block of COMPACT_KMERS (12) consecutive k-mers: {u32 first 64-byte unit of the block's rows,
+        // 16-byte block of COMPACT_KMERS (12) consecutive k-mers: {u32 first 128-byte unit of the block's rows,
         // 12 x u8 units per row}; the row offset is the block base plus a byte prefix sum (v_sad_u8 accumulates)
         const u64 idx = dense_index<BITS>(code, db.k);
         const u32 i = (u32)(idx % COMPACT_KMERS);
@@ -267,6 +271,9 @@ __device__ __forceinline__ void apply_entry(u32 *S, u32 nb, u32 br, float sc, fl
 }
 // Same update for the slot layout of the packed / ASCII kernels: word 0 of S is the scratch slot, branch x lives in
 // word x + 1, and `sb` is the word's byte offset as the row entries carry it (0 for padding).
+// MONO (every score of the database is >= the threshold, so every increment is >= 0 and a touched word never drops
+// below Q*T): the first-touch test is one v_max with the -inf marker.
+template <bool MONO = false>
 __device__ __forceinline__ void apply_slot(u32 *S, u32 sb, float sc, float QT, float T) {
     if (RK_ABLATE & 8) {
         asm volatile("" ::"v"(sb), "v"(sc));
@@ -274,7 +281,9 @@ __device__ __forceinline__ void apply_slot(u32 *S, u32 sb, float sc, float QT, f
     }
     u32 *p = (u32 *)((unsigned char *)S + sb);
     const u32 old = *p;
-    const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+    float base;
+    if (MONO) asm("v_max_f32 %0, %1, %2" : "=v"(base) : "v"(old), "v"(QT));  // plain max: no NaNs here, no canonicalize
+    else base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
     const float d = sc - T;
     const float nw = base + d;
     *p = __float_as_uint(nw);
@@ -372,15 +381,13 @@ __device__ __forceinline__ void accumulate_chunks(u32 *S, u32 nb, const typename
 }
 
 // ------------------------------------------------------------------------------------------------
-// accumulate, G == 16 with 32-bit offsets (the usual geometry): a chunk is one or two 64-byte lines and its item is
-//   byte offset of the first line | ITEM_ONE_LINE (bit 31) when the second line does not belong to the row.
-// Rows are read through a raw buffer descriptor over the blob: lanes 0-7 clear bit 31, lanes 8-15 keep it, so
-// for a one-line chunk their offset falls outside the buffer -- the load returns zeros without touching memory and
-// the update goes to the scratch slot.  List slots past a group's own count hold ITEM_FILLER (out of range for
-// both halves), so a step is: item & lane mask, + lane offset, one buffer load, one LDS read-modify-write --
-// no bounds test, no count test, no 64-bit address arithmetic.  `wcnt` = the largest count among the wave's groups.
+// accumulate, G == 16 with 32-bit offsets (the usual geometry): rows are stored in aligned 128-byte units of 16
+// entries, so a chunk is exactly one unit -- one 128-byte request for the group -- and its item is just the unit's
+// byte offset.  Rows are read through a raw buffer descriptor over the blob; list slots past a group's own count
+// hold ITEM_FILLER, an offset outside the buffer: the load returns zeros without touching memory and the update
+// goes to the scratch slot.  A step is then: item + lane offset, one buffer load, one LDS read-modify-write -- no
+// bounds test, no count test, no 64-bit address arithmetic.  `wcnt` = the largest count among the wave's groups.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 ITEM_ONE_LINE = 0x80000000u;
 constexpr u32 ITEM_FILLER = 0xFFFFFF00u;
 typedef u32 v2u32 __attribute__((ext_vector_type(2)));
 
@@ -388,15 +395,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_resource(const DbView &db
     return __builtin_amdgcn_make_buffer_rsrc((void *)db.rows, (short)0, (int)(u32)db.rows_bytes, 0x00020000);
 }
 
-template <int U>
+template <int U, bool MONO>
 __device__ __forceinline__ void accumulate_chunks16(u32 *S, const u32 *items, int wcnt, u32 li,
                                                     __amdgpu_buffer_rsrc_t rs, float QT, float T) {
-    const u32 amask = (li & 8u) ? 0xFFFFFFFFu : ~ITEM_ONE_LINE;
     const u32 li8 = li * 8;
     u32 sb[U], it[U];
     float sc[U];
     auto issue = [&](u32 item, u32 &b, float &v) {
-        u32 off = (item & amask) + li8;
+        u32 off = item + li8;
         if (RK_ABLATE & 16) off = li8;
         const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
         b = e.x;
@@ -410,7 +416,7 @@ __device__ __forceinline__ void accumulate_chunks16(u32 *S, const u32 *items, in
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_slot(S, sb[u], sc[u], QT, T);
+            apply_slot<MONO>(S, sb[u], sc[u], QT, T);
             issue(it[u], sb[u], sc[u]);
             it[u] = items[s0 + 2 * U + u];
         }
@@ -490,7 +496,7 @@ __device__ __forceinline__ int rank_candidates(const u64 *list, int c, u64 *win,
 }
 
 // Scans S[0..nb) with the G lanes of a group and resets it to UNTOUCHED; leaves the rank-r winner key in lane r.
-//   pass 1  per-lane maximum, 4 scores per LDS read (float compare; the UNTOUCHED pattern is a NaN and never wins);
+//   pass 1  per-lane maximum, 4 scores per LDS read (float compare; the -inf UNTOUCHED marker never wins);
 //   tau     the K-th largest of the G lane maxima: at least K scores are >= tau, so it bounds the answer from below;
 //   pass 2  entries with key >= tau are compacted into the (now idle) hit list while S is reset, 4 per LDS access;
 //           if the list fills up it is pruned to its exact top-K and tau is raised -- correct for any distribution;
@@ -498,7 +504,7 @@ __device__ __forceinline__ int rank_candidates(const u64 *list, int c, u64 *win,
 // `list` has `cap` u64 slots; the last 16 are the winners' scratch.  S must be 16-byte aligned with s_stride % 4 == 0
 // (slots in [nb, s_stride) are scratch).  Returns numBest (group-uniform).
 template <int G>
-__device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+__device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key RK_STAMP_PARAMS) {
     // slot layout: S[0] is the scratch word (the caller has set it to UNTOUCHED), branch x is S[x + 1], ns = n_branches + 1
     const u32 nb = ns;
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
@@ -516,7 +522,7 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, 
         const float v[4] = {__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w)};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const bool gt = (v[e] > mo) && (i + e < nb);  // false for the NaN marker; ties keep the smaller branch id
+            const bool gt = (v[e] > mo) && (i + e < nb);  // false for the -inf marker; ties keep the smaller branch id
             mo = gt ? v[e] : mo;
             mi = gt ? i + e : mi;
         }
@@ -568,36 +574,68 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, 
     return num;
 }
 
-// Fast select: ONE pass over S.  Every lane keeps its three best (score, branch) pairs in registers plus the best
-// score it had to drop; K rounds of group-max over the lane heads then give the exact top-K unless some lane might
-// still hide a better entry (it dropped something >= the K-th winner) -- rare (a lane would need >= 4 of the top K);
-// then the exact two-pass scan above runs instead.  S is reset with plain 16-byte stores afterwards.
+// group-wide maxima of a 32-bit value.  G == 16: a group is one DPP row, four rotate-and-max steps, no LDS traffic.
 template <int G>
-__device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key) {
+__device__ __forceinline__ float group_max_f32(float v) {
+    if (G == 16) {
+        v = fmaxf(v, __uint_as_float(row_ror32<8>(__float_as_uint(v))));
+        v = fmaxf(v, __uint_as_float(row_ror32<4>(__float_as_uint(v))));
+        v = fmaxf(v, __uint_as_float(row_ror32<2>(__float_as_uint(v))));
+        v = fmaxf(v, __uint_as_float(row_ror32<1>(__float_as_uint(v))));
+    } else {
+#pragma unroll
+        for (int s = 1; s < G; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, G));
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ u32 group_max_u32(u32 v) {
+    if (G == 16) {
+        v = max(v, row_ror32<8>(v));
+        v = max(v, row_ror32<4>(v));
+        v = max(v, row_ror32<2>(v));
+        v = max(v, row_ror32<1>(v));
+    } else {
+#pragma unroll
+        for (int s = 1; s < G; s <<= 1) v = max(v, (u32)__shfl_xor((int)v, s, G));
+    }
+    return v;
+}
+
+// Fast select: ONE pass over S.  Every lane keeps its three best (score, slot) pairs in registers plus the fourth-best
+// score (the best it had to drop); K rounds of group-max over the lane heads then give the exact top-K unless some
+// lane might still hide a better entry (it dropped something >= the K-th winner) -- rare (a lane would need >= 4 of
+// the top K); then the exact two-pass scan above runs instead.  A round is two 32-bit reductions: the largest head
+// score, then among the lanes holding it the smallest slot (= the order of the packed key: score desc, branch asc).
+// S is reset with plain 16-byte stores afterwards.
+template <int G>
+__device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key RK_STAMP_PARAMS) {
     // slot layout: the scratch word S[0] leaves the competition, then the scan runs over ns = n_branches + 1 slots and
     // slot i stands for branch i - 1
     if (li == 0) S[0] = S_UNTOUCHED;
     wave_lds_fence();
     const u32 nb = n_branches + 1;
-    if (K > 8) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key);
+    if (K > 8) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     const uint4 *S4 = (const uint4 *)S;
     uint4 *S4w = (uint4 *)S;
     const u32 n4 = (nb + 3) / 4;
-    float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
+    float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, s3 = -INFINITY;
     u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
-    // sorted insertion into the lane's top three; strict '>' keeps the smaller branch id ahead among equal scores and
-    // is false for the NaN marker of untouched branches
-    auto feed = [&](float v, u32 idx, bool in) {
-        const bool g0 = in && v > s0, g1 = in && v > s1, g2 = in && v > s2;
-        const float drop = g2 ? s2 : (in ? v : -INFINITY);
-        lost = fmaxf(lost, drop);  // fmaxf ignores the NaN marker
-        s2 = g1 ? s1 : (g2 ? v : s2);
-        i2 = g1 ? i1 : (g2 ? idx : i2);
-        s1 = g0 ? s0 : (g1 ? v : s1);
-        i1 = g0 ? i0 : (g1 ? idx : i1);
-        s0 = g0 ? v : s0;
+    // sorted insertion into the lane's top three (s3 = best dropped score); strict '>' keeps the smaller slot ahead among
+    // equal scores and is false for the -inf marker of untouched branches
+    auto feed = [&](float v, u32 idx) {
+        // (one select per statement: nested conditionals came out of hipcc as divergent branches)
+        const bool g0 = v > s0, g1 = v > s1, g2 = v > s2;
+        const u32 t2 = g2 ? idx : i2;
+        i2 = g1 ? i1 : t2;
+        const u32 t1 = g1 ? idx : i1;
+        i1 = g0 ? i0 : t1;
         i0 = g0 ? idx : i0;
+        s3 = __builtin_amdgcn_fmed3f(v, s2, s3);
+        s2 = __builtin_amdgcn_fmed3f(v, s1, s2);
+        s1 = __builtin_amdgcn_fmed3f(v, s0, s1);
+        s0 = g0 ? v : s0;
     };
     const u32 n4_full = nb / 4;  // quads that lie entirely below nb need no bounds test
     if (li < n4_full) {
@@ -606,39 +644,49 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 g
             const uint4 v4 = cur;
             if (q + G < n4_full) cur = S4[q + G];  // next quad is in flight while this one is ranked
             const u32 i = 4 * q;
-            feed(__uint_as_float(v4.x), i, true);
-            feed(__uint_as_float(v4.y), i + 1, true);
-            feed(__uint_as_float(v4.z), i + 2, true);
-            feed(__uint_as_float(v4.w), i + 3, true);
+            feed(__uint_as_float(v4.x), i);
+            feed(__uint_as_float(v4.y), i + 1);
+            feed(__uint_as_float(v4.z), i + 2);
+            feed(__uint_as_float(v4.w), i + 3);
         }
     }
     if ((nb & 3u) && (n4_full % G) == li) {  // the partial last quad
         const uint4 v4 = S4[n4_full];
         const u32 i = 4 * n4_full;
-        feed(__uint_as_float(v4.x), i, i < nb);
-        feed(__uint_as_float(v4.y), i + 1, i + 1 < nb);
-        feed(__uint_as_float(v4.z), i + 2, i + 2 < nb);
-        feed(__uint_as_float(v4.w), i + 3, i + 3 < nb);
+        feed(i < nb ? __uint_as_float(v4.x) : -INFINITY, i);
+        feed(i + 1 < nb ? __uint_as_float(v4.y) : -INFINITY, i + 1);
+        feed(i + 2 < nb ? __uint_as_float(v4.z) : -INFINITY, i + 2);
+        feed(i + 3 < nb ? __uint_as_float(v4.w) : -INFINITY, i + 3);
     }
-    u64 k0 = (i0 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s0), i0 - 1u) : 0ull;
-    u64 k1 = (i1 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s1), i1 - 1u) : 0ull;
-    u64 k2 = (i2 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s2), i2 - 1u) : 0ull;
-    win_key = 0;
+    RK_STAMP(8);
+    // rounds run on the order-preserving integer image of the scores: integer max folds into the DPP rotate
+    constexpr u32 ORD_NEG_INF = 0x007FFFFFu;  // ord_f32(-inf)
+    u32 o0 = ord_f32(s0), o1 = ord_f32(s1), o2 = ord_f32(s2);
+    u32 win_o = 0, win_i = 0, last = ORD_NEG_INF;
     int num = 0;
-    u64 last = 0;
     for (int r = 0; r < K; r++) {
-        const u64 m = group_max<G>(k0);
-        if (m == 0) break;  // group-uniform
-        num++;
-        last = m;
-        if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }  // unique winner pops its head
-        if ((int)li == r) win_key = m;
+        const u32 m = group_max_u32<G>(o0);
+        const bool valid = m != ORD_NEG_INF;  // group-uniform: something is left
+        const bool head = valid && o0 == m;
+        const u32 w = group_max_u32<G>(head ? ~i0 : 0u);  // smallest slot among the lanes holding m
+        const bool pop = head && ~i0 == w;                // exactly one lane
+        const bool mine = (int)li == r && valid;
+        win_o = mine ? m : win_o;
+        win_i = mine ? ~w : win_i;
+        num += valid ? 1 : 0;
+        last = valid ? m : last;
+        o0 = pop ? o1 : o0; i0 = pop ? i1 : i0;
+        o1 = pop ? o2 : o1; i1 = pop ? i2 : i1;
+        o2 = pop ? ORD_NEG_INF : o2; i2 = pop ? 0xFFFFFFFFu : i2;
     }
     // could a dropped entry belong to the answer?  K ranks filled: only if it ties or beats the weakest winner;
     // fewer than K ranks filled: any dropped entry at all
-    const bool doubt = (num == K) ? (lost >= unord_f32((u32)(last >> 32))) : (lost > -INFINITY);
+    const u32 o3 = ord_f32(s3);
+    const bool doubt = (num == K) ? (o3 >= last) : (o3 != ORD_NEG_INF);
     if (((__ballot(doubt) >> (gi * G)) & gmask) != 0)  // group-uniform
-        return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key);
+        return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
+    win_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
+    RK_STAMP(9);
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
     return num;
@@ -670,7 +718,10 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
         double sum = 0.0;
         for (int q = numBest - 1; q >= 0; q--) sum += shfl_f64(term, q, G);
         float shift2 = (-308.0f >= lowest) ? best : 0.0f;  // :978-980 uses the true minimum
-        double ratio = mine ? exp10((double)score - (double)shift2) / sum : 0.0;  // :392-394 (Math.pow(10.0, x))
+        // :392-394 Math.pow(10.0, (double)score - (double)shift2): the same number as `term` unless a shift is in play
+        double numer = term;
+        if (__any(shift != 0.0f || shift2 != 0.0f)) numer = mine ? exp10((double)score - (double)shift2) : 0.0;
+        double ratio = mine ? numer / sum : 0.0;
         double best_ratio = shfl_f64(ratio, 0, G);
         bool fail = mine && li > 0 && (ratio < best_ratio * (double)a.keep_factor);  // :998-1000
         u64 fb = __ballot(fail);
@@ -734,7 +785,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
     const u64 wave_count = (u64)gridDim.x * waves_per_block;
 #ifdef RK_STAMPS
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_ = rk_now();
 #endif
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
@@ -774,7 +825,10 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                 for (int i = cnt + (int)li; i < wcnt + 2 * U; i += G) ((u32 *)items)[i] = ITEM_FILLER;
                 wave_lds_fence();
                 RK_STAMP(3);
-                if (!(RK_ABLATE & 1)) accumulate_chunks16<U>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
+                if (!(RK_ABLATE & 1)) {
+                    if (a.db.mono) accumulate_chunks16<U, true>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
+                    else accumulate_chunks16<U, false>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
+                }
                 wave_lds_fence();
                 RK_STAMP(4);
                 cnt = 0;
@@ -893,12 +947,12 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;
                     const int base = cnt + (int)excl[u];
                     if (FAST16) {
-                        const u32 rb = (u32)off8 * 8u;  // byte offset of the row (64-byte aligned)
+                        const u32 rb = (u32)off8 * 8u;  // byte offset of the row (128-byte aligned units)
                         u32 *it32 = (u32 *)items;
-                        if (nch[u] > 0) it32[base] = rb | (lenp <= 8u ? ITEM_ONE_LINE : 0u);
-                        if (nch[u] > 1) it32[base + 1] = (rb + 128u) | (lenp <= 24u ? ITEM_ONE_LINE : 0u);
+                        if (nch[u] > 0) it32[base] = rb;
+                        if (nch[u] > 1) it32[base + 1] = rb + 128u;
                         for (u32 c = 2; __any(c < nch[u]); c++)
-                            if (c < nch[u]) it32[base + (int)c] = (rb + c * 128u) | (lenp - c * 16u <= 8u ? ITEM_ONE_LINE : 0u);
+                            if (c < nch[u]) it32[base + (int)c] = rb + c * 128u;
                         continue;
                     }
                     // most rows are 1-2 chunks: those are written without a wave vote, the rest in a voted loop
@@ -922,7 +976,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         u64 win_key;
         int numBest = 0;
         if (RK_ABLATE & 2) { win_key = list[0]; for (u32 i = li; i <= nb; i += G) S[i] = S_UNTOUCHED; }
-        else numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
+        else numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key RK_STAMP_ARGS);
         wave_lds_fence();
         RK_STAMP(5);  // select
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
@@ -932,7 +986,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     }
 #ifdef RK_STAMPS
     if (lane == 0 && wave_global < 4096)
-        for (int i = 0; i < 8; i++) rk_stamp_buf[wave_global * 8 + i] = st_[i];
+        for (int i = 0; i < 16; i++) rk_stamp_buf[wave_global * 16 + i] = st_[i];
 #endif
 }
 
@@ -1428,7 +1482,10 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
             flush();
             wave_lds_fence();
             u64 win_key;
-            int numBest = select_topk<64>(S, nb, lane, 0u, (int)a.keep_at_most, clist, ASCII_LIST_CAP, win_key);
+#ifdef RK_STAMPS
+            unsigned long long st_[16] = {0}, t_ = 0;
+#endif
+            int numBest = select_topk<64>(S, nb, lane, 0u, (int)a.keep_at_most, clist, ASCII_LIST_CAP, win_key RK_STAMP_ARGS);
             wave_lds_fence();
             weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
         }

@@ -24,13 +24,17 @@ pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
 pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
 lib = ra._lib.load()
 nw = 2048
-buf = (C.c_ulonglong * (nw * 8))()
+buf = (C.c_ulonglong * (nw * 16))()
 lib.rk_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.rk_debug_read_stamps(buf, nw) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 8).astype(np.float64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 16).astype(np.float64)
 tot = a.sum(1)
-names = ["tile setup", "probe (codes+gathers)", "scan+emit items", "pre-accumulate fence", "accumulate", "select", "weigh+store", "-"]
+names = ["tile setup", "probe (codes+gathers)", "scan+emit items", "pre-accumulate fence", "accumulate", "select (rest: reset)", "weigh+store", "-",
+         "select: scan", "select: rounds"]
+a = a[tot > 0]
+tot = tot[tot > 0]
+nw = len(tot)
 print(db.kernel_name())
 print("median wave cycles:", np.median(tot), " per tile:", np.median(tot) / (n / 4 / nw))
-for i, nm in enumerate(names[:7]):
+for i, nm in enumerate(names):
     print(f"  {nm:24s} {100 * np.median(a[:, i] / tot):5.1f} %   {np.median(a[:, i]) / (n / 4 / nw):8.0f} cycles/tile")

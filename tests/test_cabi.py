@@ -100,8 +100,8 @@ def test_db_validate_builds_image_without_device():
     assert info.n_keys == sdb.n_keys and info.n_entries == sdb.n_entries
     lens = np.diff(sdb.row_offsets.astype(np.int64))
     assert info.max_row_len == lens.max()
-    lines = ((lens + 7) // 8).sum() + 1                     # rows padded to whole 64-byte lines + the reserved line 0
-    assert info.rows_bytes == lines * 64
+    units = ((lens + 15) // 16).sum() + 1                   # rows padded to whole 128-byte units + the reserved unit 0
+    assert info.rows_bytes == units * 128
     assert info.table_bytes == ((4 ** 8 + 11) // 12) * 16   # compact table: 16 bytes per 12 k-mers
     assert _validate(sdb, table_mode=_lib.RK_TABLE_DIRECT8).table_bytes == 4 ** 8 * 8
     h = _validate(sdb, table_mode=_lib.RK_TABLE_HASH)
@@ -113,7 +113,8 @@ def test_db_validate_builds_image_without_device():
     bl = np.diff(big.row_offsets.astype(np.int64))
     # [index line][u16 branch[lenp]][f32 score[lenp]] with lenp padded to 32 entries: 6 bytes per entry
     assert bi.table_mode == _lib.RK_TABLE_DIRECT8 and bi.rows_bytes == ((((bl + 31) // 32 * 32) * 6 // 64).sum() + len(bl) + 1) * 64
-    long_rows = synth.make_db(4, 6, 4000, 50, 150000, seed=3)  # rows > 2040 entries do not fit the compact table
+    long_rows = synth.make_db(4, 6, 8000, 30, 200000, seed=3)  # rows > 4080 entries do not fit the compact table
+    assert np.diff(long_rows.row_offsets.astype(np.int64)).max() > 4080
     assert _validate(long_rows).table_mode == _lib.RK_TABLE_DIRECT8
 
 

@@ -295,3 +295,20 @@ def test_device_api_pack_and_place(c2_small):
         assert (getattr(host, f) == getattr(got, f)).all()
     assert (host.score.view(np.uint32) == got.score.view(np.uint32)).all() and (host.lwr == got.lwr).all()
     db.close()
+
+
+@pytest.mark.parametrize("lanes", [0, 32])
+@pytest.mark.parametrize("amb", ["mean", "max"])
+def test_scores_below_threshold_take_the_general_first_touch(lanes, amb):
+    """A database RAPPAS would not write (some scores < log10 threshold, i.e. negative increments): the engine must not
+    use the max() first-touch shortcut that is valid only when every increment is >= 0."""
+    import dataclasses
+    sdb = synth.make_config_db("C2", scale=0.1)
+    rng = np.random.default_rng(5)
+    sc = sdb.scores.copy()
+    low = rng.random(sc.shape[0]) < 0.3
+    sc[low] = (sdb.thr_log10 * (1.0 + 3.0 * rng.random(int(low.sum()), dtype=np.float32))).astype(np.float32)
+    assert (sc < sdb.thr_log10).sum() > 1000
+    sdb = dataclasses.replace(sdb, scores=sc)
+    seq, off = synth.make_reads(4, 3000, 150, seed=4, amb_rate=0.001)
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", lanes, amb)
