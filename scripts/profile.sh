@@ -18,4 +18,9 @@ run pmc1 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_
 run pmc2 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_WAVES &&
 run pmc3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE &&
 run pmc4 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-find "$OUT" -name "*.csv" | head -30
+if [ -n "${PROF_PREFIX:-}" ]; then  # summarise, keep only the summaries (raw traces exceed the 64 MiB merge limit)
+  python3 "$ROOT/scripts/prof_summary.py" "$OUT" "$ROOT/gpurun_out/$PROF_PREFIX"
+  rm -rf "$OUT"
+else
+  find "$OUT" -name "*.csv" | head -30
+fi
