@@ -160,6 +160,50 @@ int rk_set_lanes_per_read(rk_db *db, uint32_t lanes);
 /* Name of the placement kernel variant the next launch will use (for profiles). */
 const char *rk_kernel_name(const rk_db *db);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Phylo-kmer database construction (`-p b` hot loop).
+ * Replaces, for one reference tree, the triple loop of src/main_v2/Main_DBBUILD_3.java:648-750 -- for every tested node,
+ * for every alignment position pos in [0, L-k+2), a fresh src/core/algos/WordExplorer_v3.java explorer (:98-199: the
+ * branch-and-bound recursion with its running float32 sum) started from every state rank -- together with the insertions
+ * of src/core/hash/CustomHash_v4_FastUtil81.java:73-89 (addTuple: per (k-mer, original branch) keep the largest PP*).
+ * Input is what src/core/PProbasSorted.java:19-25 holds after the ancestral reconstruction has been parsed: per node and
+ * site the states ranked by descending posterior, with log10 posteriors.  Output is the CSR form rk_db_create takes
+ * (keys ascending, branches ascending inside a row), in host memory owned by the library.  The reference's
+ * registered scores depend on the order of exploration (a running float is incremented and decremented); the kernel
+ * replays each explorer's statements in order, one lane per (node, pos), so the scores are bit-identical.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct rk_build_desc {
+    uint32_t alphabet;            /* RK_ALPHABET_DNA | RK_ALPHABET_AA (word -> key code as for rk_db_desc.key_codes) */
+    uint32_t k;                   /* DNA: 2..15, AA: 2..9 (code << 16 | branch must fit 64 bits) */
+    uint32_t n_nodes;             /* tested nodes = rows of the posterior table (Main_DBBUILD_3.java:648 nodesTested) */
+    uint32_t n_sites;             /* alignment length == PProbasSorted.getSiteCount() */
+    uint32_t n_states;            /* PProbasSorted.getStateCount() */
+    uint32_t do_gap_jumps;        /* gapJumpsActivated (Main_DBBUILD_3.java:239-258) */
+    uint32_t limit_to_1_jump;     /* ArgumentsParser_v2.java:76 (default true) */
+    float thr_log10;              /* session.PPStarThresholdAsLog10 */
+    const uint8_t *states;        /* [n_nodes][n_sites][n_states] PProbasSorted.states */
+    const float *pp_log10;        /* [n_nodes][n_sites][n_states] PProbasSorted.pp, descending along the last axis */
+    const uint16_t *node_branch;  /* [n_nodes] original branch id of each tested node (WordExplorer_v3.java:93-94) */
+    const uint32_t *gap_off;      /* [n_sites+1] CSR over sites of Alignment.getGapIntervals(); NULL unless do_gap_jumps */
+    const int32_t *gap_len;       /* interval lengths */
+    int32_t device;               /* HIP device ordinal */
+    uint32_t reserved;
+} rk_build_desc;
+
+typedef struct rk_built_db {
+    uint64_t n_keys, n_entries;
+    uint64_t *key_codes;          /* [n_keys] ascending */
+    uint64_t *row_offsets;        /* [n_keys+1] */
+    uint16_t *branch_ids;         /* [n_entries] ascending inside a row */
+    float *scores;                /* [n_entries] */
+    uint64_t tuples;              /* addTuple calls ("Tuples explored", Main_DBBUILD_3.java:760) */
+    uint64_t visits;              /* exploreWords calls that passed the alignment-limit test */
+    double explore_ms, reduce_ms; /* device time of the two stages (HIP events) */
+} rk_built_db;
+
+int rk_build_db(const rk_build_desc *desc, rk_built_db *out);
+void rk_built_free(rk_built_db *b);
+
 #ifdef __cplusplus
 }
 #endif

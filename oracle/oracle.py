@@ -23,7 +23,7 @@ class ro_counters(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, f) for f in ("rappas_oracle.c", "rappas_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("rappas_oracle.c", "rappas_oracle.h", "rappas_build_oracle.c", "rappas_build_oracle.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
         subprocess.run(["make", "-C", HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
     return SO
@@ -145,3 +145,52 @@ class OracleDB:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# phylo-kmer DB construction (rappas_build_oracle.c): Main_DBBUILD_3.java:648-750 + WordExplorer_v3 + addTuple
+# ---------------------------------------------------------------------------------------------------------------
+class ro_build_desc(C.Structure):
+    _fields_ = [("alphabet", C.c_int), ("k", C.c_int), ("n_nodes", C.c_int), ("n_sites", C.c_int), ("n_states", C.c_int),
+                ("states", C.c_void_p), ("pp", C.c_void_p), ("node_branch", C.c_void_p), ("thr_log10", C.c_float),
+                ("do_gap_jumps", C.c_int), ("limit_to_1_jump", C.c_int), ("gap_off", C.c_void_p), ("gap_len", C.c_void_p)]
+
+
+class ro_built(C.Structure):
+    _fields_ = [("n_keys", C.c_uint64), ("key_codes", C.POINTER(C.c_uint64)), ("row_offsets", C.POINTER(C.c_uint64)),
+                ("branch_ids", C.POINTER(C.c_uint16)), ("scores", C.POINTER(C.c_float)), ("tuples", C.c_uint64),
+                ("visits", C.c_uint64)]
+
+
+def build_db(alphabet, k, states, pp, node_branch, thr_log10, gap_off=None, gap_len=None, limit_to_1_jump=True):
+    """states u8 / pp f32: [n_nodes, n_sites, n_states] (rank-ordered, PProbasSorted); node_branch u16 [n_nodes].
+    -> dict(key_codes, row_offsets, branch_ids, scores, tuples, visits); rows sorted by code, entries by branch."""
+    L = load()
+    L.ro_build_db.restype = C.c_int
+    L.ro_build_db.argtypes = [C.POINTER(ro_build_desc), C.POINTER(ro_built)]
+    L.ro_built_free.argtypes = [C.POINTER(ro_built)]
+    states = np.ascontiguousarray(states, np.uint8)
+    pp = np.ascontiguousarray(pp, np.float32)
+    node_branch = np.ascontiguousarray(node_branch, np.uint16)
+    n_nodes, n_sites, n_states = states.shape
+    assert pp.shape == states.shape and node_branch.shape == (n_nodes,)
+    gaps = gap_off is not None
+    if gaps:
+        gap_off = np.ascontiguousarray(gap_off, np.uint32)
+        gap_len = np.ascontiguousarray(gap_len, np.int32)
+        assert gap_off.shape == (n_sites + 1,)
+    d = ro_build_desc(alphabet, k, n_nodes, n_sites, n_states, _p(states), _p(pp), _p(node_branch), float(thr_log10),
+                      int(gaps), int(bool(limit_to_1_jump)), _p(gap_off) if gaps else None, _p(gap_len) if gaps else None)
+    b = ro_built()
+    rc = L.ro_build_db(C.byref(d), C.byref(b))
+    if rc:
+        raise RuntimeError(f"ro_build_db failed: {rc}")
+    try:
+        nk = int(b.n_keys)
+        off = np.ctypeslib.as_array(b.row_offsets, (nk + 1,)).copy()
+        ne = int(off[-1])
+        return dict(key_codes=np.ctypeslib.as_array(b.key_codes, (max(nk, 1),))[:nk].copy(), row_offsets=off,
+                    branch_ids=np.ctypeslib.as_array(b.branch_ids, (max(ne, 1),))[:ne].copy(),
+                    scores=np.ctypeslib.as_array(b.scores, (max(ne, 1),))[:ne].copy(), tuples=int(b.tuples), visits=int(b.visits))
+    finally:
+        L.ro_built_free(C.byref(b))

@@ -43,6 +43,23 @@ class rk_result(C.Structure):
     _fields_ = [("n_rows", C.c_void_p), ("branch", C.c_void_p), ("score", C.c_void_p), ("lwr", C.c_void_p), ("flags", C.c_void_p)]
 
 
+class rk_build_desc(C.Structure):
+    _fields_ = [
+        ("alphabet", C.c_uint32), ("k", C.c_uint32), ("n_nodes", C.c_uint32), ("n_sites", C.c_uint32), ("n_states", C.c_uint32),
+        ("do_gap_jumps", C.c_uint32), ("limit_to_1_jump", C.c_uint32), ("thr_log10", C.c_float),
+        ("states", C.c_void_p), ("pp_log10", C.c_void_p), ("node_branch", C.c_void_p), ("gap_off", C.c_void_p),
+        ("gap_len", C.c_void_p), ("device", C.c_int32), ("reserved", C.c_uint32),
+    ]
+
+
+class rk_built_db(C.Structure):
+    _fields_ = [
+        ("n_keys", C.c_uint64), ("n_entries", C.c_uint64), ("key_codes", C.POINTER(C.c_uint64)),
+        ("row_offsets", C.POINTER(C.c_uint64)), ("branch_ids", C.POINTER(C.c_uint16)), ("scores", C.POINTER(C.c_float)),
+        ("tuples", C.c_uint64), ("visits", C.c_uint64), ("explore_ms", C.c_double), ("reduce_ms", C.c_double),
+    ]
+
+
 # every symbol include/rappas_place.h declares
 EXPORTS = {
     "rk_version": (C.c_int, []),
@@ -64,6 +81,8 @@ EXPORTS = {
                                          C.POINTER(rk_result), C.c_void_p]),
     "rk_set_lanes_per_read": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rk_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "rk_build_db": (C.c_int, [C.POINTER(rk_build_desc), C.POINTER(rk_built_db)]),
+    "rk_built_free": (None, [C.POINTER(rk_built_db)]),
 }
 
 
@@ -89,6 +108,8 @@ def load():
         pass
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in EXPORTS.items():
+        if name.startswith("rk_buil") and os.environ.get("RK_LIB") and not hasattr(lib, name):
+            continue  # developer timing builds (scripts/) compile the placement unit only
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -39,13 +39,30 @@ def engine_sources():
 
 
 def build_engine(force=False, verbose=False):
+    """One object per .hip translation unit (compiled side by side), then one shared library."""
     srcs = engine_sources()
     if not force and not _stale(ENGINE_SO, srcs):
         return ENGINE_SO
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", ENGINE_SO, os.path.join(CSRC, "rk_engine.hip")]
+    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and f != "rk_kernels.hip"]  # rk_kernels.hip is #included by rk_engine.hip
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    procs = []
+    for u in units:
+        obj = os.path.join(objdir, u.replace(".hip", ".o"))
+        cmd = [_hipcc()] + flags + ["-c", "-o", obj, os.path.join(CSRC, u)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=ROOT)))
+    objs = []
+    for cmd, obj, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        objs.append(obj)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", ENGINE_SO] + objs
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=ROOT)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=ROOT)
     return ENGINE_SO
 
 

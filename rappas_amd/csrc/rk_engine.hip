@@ -2,6 +2,7 @@
 // + CSR row blob resident in HBM), launch geometry, and the C ABI of include/rappas_place.h.
 // Product path: there is NO CPU fallback in this file; every compute entry point needs a HIP device.
 #include "rk_kernels.hip"
+#include "rk_internal.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -35,6 +36,16 @@ static int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+namespace rk {
+int fail_msg(int code, const char *fmt, ...) {  // rk_internal.h: the same sink for the other translation units
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace rk
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \

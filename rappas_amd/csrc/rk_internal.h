@@ -1,0 +1,16 @@
+// rk_internal.h -- shared between the translation units of librappas_place.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rk {
+// sets the thread-local message rk_last_error() returns and hands back `code`
+int fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+}  // namespace rk
+
+#define RK_HIP_TRY(expr)                                                                                          \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return rk::fail_msg(e_ == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                                       \
+    } while (0)

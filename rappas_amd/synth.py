@@ -195,3 +195,55 @@ def make_newick(n_nodes, seed=7):
         return build(n_nodes, True) + ";"
     finally:
         sys.setrecursionlimit(old)
+
+
+def make_pp_tables(alphabet, n_nodes, n_sites, seed=3, peaked=0.8, n_branches=None):
+    """Synthetic ancestral-reconstruction output in the layout of the reference's PProbasSorted (core/PProbasSorted.java:19-25):
+    states u8 / pp f32 [n_nodes, n_sites, alphabet], per site the states ranked by descending posterior and pp = log10 of it.
+    `peaked` of the sites carry one dominant state (p in [0.9, 0.9995]), the others are diffuse, as posteriors of conserved /
+    variable columns are.  Also returns node_branch u16[n_nodes]: the original branch a tested node's k-mers are filed under
+    (two consecutive nodes share a branch, like the ghost nodes the reference hangs on every edge)."""
+    rng = np.random.default_rng(seed)
+    shape = (n_nodes, n_sites, alphabet)
+    p = rng.random(shape) ** 3 + 1e-4
+    dom = rng.random((n_nodes, n_sites)) < peaked
+    top = 0.9 + 0.0995 * rng.random((n_nodes, n_sites))
+    which = rng.integers(0, alphabet, (n_nodes, n_sites))
+    onehot = np.zeros(shape, bool)
+    np.put_along_axis(onehot, which[..., None], True, axis=2)
+    rest = np.where(onehot, 0.0, p)
+    rest = rest / rest.sum(axis=2, keepdims=True)
+    peaked_p = np.where(onehot, top[..., None], rest * (1.0 - top[..., None]))
+    diffuse_p = p / p.sum(axis=2, keepdims=True)
+    prob = np.where(dom[..., None], peaked_p, diffuse_p).astype(np.float32)
+    order = np.argsort(-prob, axis=2, kind="stable")
+    states = order.astype(np.uint8)
+    pp = np.log10(np.take_along_axis(prob, order, axis=2).astype(np.float64)).astype(np.float32)
+    nb = n_branches if n_branches is not None else max(1, (n_nodes + 1) // 2)
+    node_branch = (np.arange(n_nodes) // 2 % nb).astype(np.uint16)
+    return states, pp, node_branch
+
+
+def gap_intervals(rows):
+    """CSR form (gap_off u32[L+1], gap_len i32[...]) of Alignment.getGapIntervals() (src/alignement/Alignment.java:232-258):
+    for every alignment row, every maximal run of '-' contributes its length to the list of the site it starts at, each
+    length once per site, in order of first appearance.  A run that reaches the end of the row is never closed by a residue and
+    is not registered (updateGapIntervals only files a run when the next non-gap character is met)."""
+    L = len(rows[0])
+    lists = [[] for _ in range(L)]
+    for r in rows:
+        i = 0
+        while i < L:
+            if r[i] == "-":
+                j = i
+                while j < L and r[j] == "-":
+                    j += 1
+                if j < L and (j - i) not in lists[i]:
+                    lists[i].append(j - i)
+                i = j
+            else:
+                i += 1
+    off = np.zeros(L + 1, np.uint32)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    lens = np.array([v for x in lists for v in x], np.int32)
+    return off, lens
