@@ -29,7 +29,6 @@ namespace rk {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-constexpr int BUILD_MAX_K = 16;        // frames per lane
 constexpr int BUILD_WAVES_PER_BLOCK = 4;
 
 struct BuildArgs {
@@ -43,27 +42,119 @@ struct BuildArgs {
     float T;
     u64 n_tasks;
     u64 *task_counter;   // next explorer to hand out
-    u64 *tuple_counter;  // tuples registered so far (keeps counting past `capacity`)
+    u64 *slot_counter;   // tuple-buffer slots handed out so far, in whole chunks (keeps counting past `capacity`)
     u64 *visit_counter;
+    u64 *tuple_counter;  // addTuple calls
     u64 capacity;
     u64 *keys;           // [capacity]
     float *scores;       // [capacity]
 };
 
-// One frame per depth of the recursion (current_k): the site and pp of the node whose child loop is running, the loop
-// variable j2 and the cursor of the gap sub-loop (-1: the plain child of this j2 has not been explored yet).
+// One frame per depth of the recursion (current_k): the site and pp of the node whose child loop is running, and the loop
+// state packed in one word: j2 (bits 0-4) and the gap cursor g + 2 (bits 5-31; g == -1: the plain child of this j2 has not
+// been explored yet, g == -2: it has, gap jumps undecided).  12 bytes per frame and lane: 10.5 KB of LDS per wave.
+constexpr int BUILD_FRAMES = 14;  // inner nodes live at depths 0 .. k-2 <= 13
 struct Frames {
-    int site[BUILD_MAX_K][64];
-    float p[BUILD_MAX_K][64];
-    int j2[BUILD_MAX_K][64];
-    int g[BUILD_MAX_K][64];
-    int gend[BUILD_MAX_K][64];
+    int site[BUILD_FRAMES][64];
+    float p[BUILD_FRAMES][64];
+    int j2g[BUILD_FRAMES][64];
+};
+__device__ __forceinline__ int pack_j2g(int j2, int g) { return j2 | ((g + 2) << 5); }
+
+// addTuple (CustomHash_v4_FastUtil81.java:73): append (code << 16 | branch, score).  A wave owns a CHUNK of the tuple
+// buffer at a time (one atomic per chunk, none per registration: with a 20-letter alphabet one step in two registers
+// something somewhere in the wave); the unused tail of a chunk is filled with TUPLE_PAD, which sorts behind every real key
+// (no real key ends in 0xFFFF: branch ids are < 65535).  Any subset of the wave may be here, so the wave's cursor lives in
+// LDS, not in registers.
+constexpr int TUPLE_CHUNK = 1024;
+constexpr u64 TUPLE_PAD = ~0ull;
+struct WaveCursor {
+    u64 base;
+    int used;
+    int pad_;
 };
 
+__device__ __forceinline__ void append_tuples(const BuildArgs &a, volatile WaveCursor *wc, bool emit, u64 key, float score,
+                                              u32 lane, u64 &n_tuples) {
+    const u64 em = __ballot(emit);
+    if (!em) return;
+    const int n = __builtin_popcountll(em);
+    const int leader = __builtin_ctzll(em);
+    const int rank = __builtin_popcountll(em & ((1ull << lane) - 1));
+    u64 base = wc->base;
+    int used = wc->used;
+    if (used + n > TUPLE_CHUNK) {  // uniform: close this chunk (fewer than n <= 64 slots are left), open the next one
+        if (emit && used + rank < TUPLE_CHUNK && base + used + rank < a.capacity) a.keys[base + used + rank] = TUPLE_PAD;
+        u64 nb = 0;
+        if ((int)lane == leader) nb = atomicAdd(a.slot_counter, (u64)TUPLE_CHUNK);
+        base = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(nb >> 32), leader) << 32) |
+               (u32)__builtin_amdgcn_readlane((int)(u32)nb, leader);
+        used = 0;
+        if ((int)lane == leader) wc->base = base;
+    }
+    if (emit) {
+        const u64 slot = base + (u64)(used + rank);
+        if (slot < a.capacity) {
+            a.keys[slot] = key;
+            a.scores[slot] = score;
+        }
+        n_tuples++;
+    }
+    if ((int)lane == leader) wc->used = used + n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Explorer {  // WordExplorer_v3 fields (:37-55) of the lane's current explorer
+    float sum;
+    bool bound;
+    int boundK;
+    u64 code;
+    u64 visits;
+    u64 tuples;
+};
+
+// exploreWords(site, rank) at depth `depth` for a node with exactly L levels below it (L == 0: a leaf), without gap jumps:
+// WordExplorer_v3.java:98-157,198 as straight-line nested loops in registers -- the bottom of every explorer, where nearly
+// all visits happen.  Same statements in the same order as the frame machine of explore_kernel.
+template <int L>
+__device__ __forceinline__ void explore_tail(const BuildArgs &a, volatile WaveCursor *wc, Explorer &e, int site, int rank,
+                                             int depth, size_t node_base, u32 branch, u32 lane) {
+    if (site > (int)a.n_sites - 1) return;                                  // :109-111
+    const size_t at = node_base + (size_t)site * a.n_states + (size_t)rank;
+    const u32 st = a.states[at];
+    const float p = a.pp[at];
+    e.visits++;
+    const u32 sh = a.bits * (u32)depth;
+    e.code = (e.code & ~(((1ull << a.bits) - 1) << sh)) | ((u64)st << sh);  // :117
+    e.sum = (float)((double)e.sum + (double)p);                             // :119
+    e.bound = e.sum < a.T;                                                  // :120
+    if (e.bound) e.boundK = depth;                                          // :121-123
+    if (L == 0) {
+        append_tuples(a, wc, !e.bound, (e.code << 16) | branch, e.sum, lane, e.tuples);  // :128-138
+        e.sum = (float)((double)e.sum - (double)p);                         // :141
+        return;
+    } else {
+        for (int j2 = 0; j2 < (int)a.n_states; j2++) {                      // :147
+            if (e.bound && e.boundK == depth + 1) break;                    // :148-150
+            explore_tail<(L > 0 ? L - 1 : 0)>(a, wc, e, site + 1, j2, depth + 1, node_base, branch, lane);
+        }
+        e.sum = (float)((double)e.sum - (double)p);                         // :198
+    }
+}
+
+// INL = levels of the recursion below a node that explore_tail runs in registers (the node itself included: 1 + NS + ... +
+// NS^INL visits per transition).
+template <int INL>
 __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(BuildArgs a) {
     __shared__ Frames frames[BUILD_WAVES_PER_BLOCK];
+    __shared__ WaveCursor cursors[BUILD_WAVES_PER_BLOCK];
     const u32 lane = threadIdx.x & 63;
     Frames &F = frames[threadIdx.x >> 6];
+    volatile WaveCursor *wc = &cursors[threadIdx.x >> 6];
+    if (lane == 0) { wc->base = 0; wc->used = TUPLE_CHUNK; }  // the first registration opens the first chunk
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const int k = (int)a.k, S = (int)a.n_sites, NS = (int)a.n_states;
 
     // WordExplorer_v3 fields of the lane's current explorer
@@ -76,7 +167,7 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
     int pos = 0;
     size_t node_base = 0;  // node * n_sites * n_states
     u32 branch = 0;
-    u64 visits = 0;
+    u64 visits = 0, tuples = 0;
     bool exhausted = false;
 
     while (true) {
@@ -116,7 +207,8 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
             else d = -2;  // explorer finished
         } else if (d >= 0) {
             const int i = F.site[d][lane];
-            const int j2 = F.j2[d][lane], g = F.g[d][lane];
+            const int w = F.j2g[d][lane];
+            const int j2 = w & 31, g = (w >> 5) - 2;
             if (g == -2) {  // WordExplorer_v3.java:161-186
                 bool jump = false;
                 if (i < S - 1) {
@@ -124,17 +216,16 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
                     if (g1 > g0) {
                         if (!a.limit1) jump = true;
                         else if (firstJump == -1) { firstJump = i; jump = true; }
-                        if (jump) { F.g[d][lane] = g0; F.gend[d][lane] = g1; }
+                        if (jump) F.j2g[d][lane] = pack_j2g(j2, g0);
                     }
                 }
-                if (!jump) { F.g[d][lane] = -1; F.j2[d][lane] = j2 + 1; }
+                if (!jump) F.j2g[d][lane] = pack_j2g(j2 + 1, -1);
             } else if (g >= 0) {
-                if (g < F.gend[d][lane]) {
+                if (g < (int)a.gap_off[i + 2]) {  // end of gapIntervals[i + 1]
                     call = true; ci = (i + 1) + a.gap_len[g]; cj = j2; cd = d + 1;
-                    F.g[d][lane] = g + 1;
+                    F.j2g[d][lane] = pack_j2g(j2, g + 1);
                 } else {
-                    F.g[d][lane] = -1;
-                    F.j2[d][lane] = j2 + 1;
+                    F.j2g[d][lane] = pack_j2g(j2 + 1, -1);
                 }
             } else if (j2 >= NS || (bound && boundK == d + 1)) {  // loop end / break (:147-150)
                 const float p = F.p[d][lane];
@@ -142,15 +233,28 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
                 d = d - 1;                               // back in the caller's loop (or the driver loop)
             } else {
                 call = true; ci = i + 1; cj = j2; cd = d + 1;  // :155-157
-                if (a.do_gap) F.g[d][lane] = -2;
-                else F.j2[d][lane] = j2 + 1;
+                F.j2g[d][lane] = a.do_gap ? pack_j2g(j2, -2) : pack_j2g(j2 + 1, -1);
             }
         }
 
-        // ---- exploreWords(ci, cj) at depth cd (:98-143): leaves return at once, inner nodes open a frame ----
+        // ---- exploreWords(ci, cj) at depth cd (:98-143) ----
+        // A node with at most INL levels below it is explored to the end right here (explore_tail);
+        // higher nodes open a frame and their child loop runs through the transitions above.
         bool emit = false;
         float emit_score = 0.0f;
-        if (call && ci <= S - 1) {  // :109-111
+        const int below = k - 1 - cd;  // levels below the called node
+        if (call && !a.do_gap && below <= INL) {
+            if (cd == 0) firstJump = -1;
+            Explorer e{sum, bound, boundK, code, visits, tuples};
+            switch (below) {
+            case 0: explore_tail<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            case 1: explore_tail<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            case 2: if (INL >= 2) explore_tail<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            case 3: if (INL >= 3) explore_tail<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            default: break;
+            }
+            sum = e.sum; bound = e.bound; boundK = e.boundK; code = e.code; visits = e.visits; tuples = e.tuples;
+        } else if (call && ci <= S - 1) {  // :109-111
             if (cd == 0) firstJump = -1;  // :113-115
             const size_t at = node_base + (size_t)ci * NS + (size_t)cj;
             const u32 st = a.states[at];
@@ -165,31 +269,23 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
                 if (!bound) { emit = true; emit_score = sum; }                   // :128-138 addTuple
                 sum = (float)((double)sum - (double)p);                          // :141
             } else {
-                F.site[cd][lane] = ci; F.p[cd][lane] = p; F.j2[cd][lane] = 0; F.g[cd][lane] = -1;
+                F.site[cd][lane] = ci; F.p[cd][lane] = p; F.j2g[cd][lane] = pack_j2g(0, -1);
                 d = cd;  // its child loop runs next
             }
         }
-        // ---- register tuples: one atomic per wave ----
-        const u64 em = __ballot(emit);
-        if (em) {
-            const int n = __builtin_popcountll(em);
-            const int leader = __builtin_ctzll(em);
-            u64 base = 0;
-            if ((int)lane == leader) base = atomicAdd(a.tuple_counter, (u64)n);
-            base = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(base >> 32), leader) << 32) |
-                   (u32)__builtin_amdgcn_readlane((int)(u32)base, leader);
-            if (emit) {
-                const u64 slot = base + (u64)__builtin_popcountll(em & ((1ull << lane) - 1));
-                if (slot < a.capacity) {
-                    a.keys[slot] = (code << 16) | branch;
-                    a.scores[slot] = emit_score;
-                }
-            }
-        }
+        append_tuples(a, wc, emit, (code << 16) | branch, emit_score, lane, tuples);
+    }
+    // pad the unused tail of the wave's last chunk
+    {
+        const u64 base = wc->base;
+        for (int i = wc->used + (int)lane; i < TUPLE_CHUNK; i += 64)
+            if (base + (u64)i < a.capacity) a.keys[base + (u64)i] = TUPLE_PAD;
     }
     // per-wave visit count
     for (int s = 32; s > 0; s >>= 1) visits += __shfl_xor(visits, s, 64);
+    for (int s = 32; s > 0; s >>= 1) tuples += __shfl_xor(tuples, s, 64);
     if (lane == 0 && visits) atomicAdd(a.visit_counter, visits);
+    if (lane == 0 && tuples) atomicAdd(a.tuple_counter, tuples);
 }
 
 struct ShiftRight16 {
@@ -240,6 +336,8 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
         if (d->states[i] >= d->alphabet) return fail_msg(RK_ERR_INVALID, "rk_build_db: state %u at cell %zu is not a state of the alphabet", d->states[i], i);
         if (std::isnan(d->pp_log10[i])) return fail_msg(RK_ERR_INVALID, "rk_build_db: NaN posterior at cell %zu", i);
     }
+    for (u32 i = 0; i < d->n_nodes; i++)
+        if (d->node_branch[i] == 0xFFFFu) return fail_msg(RK_ERR_INVALID, "rk_build_db: node %u: branch id 65535 is reserved", i);
     size_t n_gap = 0;
     if (d->do_gap_jumps) {
         for (u32 i = 0; i < d->n_sites; i++)
@@ -261,7 +359,7 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     DevBuf b_states, b_pp, b_nb, b_goff, b_glen, b_cnt;
     int rc;
     if ((rc = b_states.alloc(cells)) || (rc = b_pp.alloc(cells * 4)) || (rc = b_nb.alloc((size_t)d->n_nodes * 2)) ||
-        (rc = b_goff.alloc(((size_t)d->n_sites + 2) * 4)) || (rc = b_glen.alloc(n_gap * 4)) || (rc = b_cnt.alloc(3 * 8)))
+        (rc = b_goff.alloc(((size_t)d->n_sites + 2) * 4)) || (rc = b_glen.alloc(n_gap * 4)) || (rc = b_cnt.alloc(4 * 8)))
         return rc;
     RK_HIP_TRY(hipMemcpy(b_states.p, d->states, cells, hipMemcpyHostToDevice));
     RK_HIP_TRY(hipMemcpy(b_pp.p, d->pp_log10, cells * 4, hipMemcpyHostToDevice));
@@ -280,7 +378,8 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     a.k = d->k; a.bits = bits; a.n_nodes = d->n_nodes; a.n_sites = d->n_sites; a.n_states = d->n_states; a.n_pos = n_pos;
     a.do_gap = d->do_gap_jumps ? 1u : 0u; a.limit1 = d->limit_to_1_jump ? 1u : 0u;
     a.T = d->thr_log10; a.n_tasks = n_tasks;
-    a.task_counter = b_cnt.as<u64>(); a.tuple_counter = a.task_counter + 1; a.visit_counter = a.task_counter + 2;
+    a.task_counter = b_cnt.as<u64>(); a.slot_counter = a.task_counter + 1; a.visit_counter = a.task_counter + 2;
+    a.tuple_counter = a.task_counter + 3;
 
     hipEvent_t e0, e1, e2;
     RK_HIP_TRY(hipEventCreate(&e0)); RK_HIP_TRY(hipEventCreate(&e1)); RK_HIP_TRY(hipEventCreate(&e2));
@@ -290,29 +389,40 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     DevBuf b_keys, b_scores;
     u64 capacity = n_tasks * 64 + (1u << 20);
     if (capacity > (1ull << 28)) capacity = 1ull << 28;
-    u64 counters[3] = {0, 0, 0};
-    const unsigned blocks = (unsigned)prop.multiProcessorCount * 4;  // persistent: 16 waves per CU (LDS: 20 KB per wave)
+    u64 counters[4] = {0, 0, 0, 0};  // tasks, slots, visits, tuples
+    const unsigned blocks = (unsigned)prop.multiProcessorCount * 3;  // persistent: 12 waves per CU (LDS: 10.5 KB per wave)
+    const u64 chunk_slack = (u64)blocks * BUILD_WAVES_PER_BLOCK * TUPLE_CHUNK;  // every wave may leave one chunk half empty
+    capacity += chunk_slack;
     float explore_ms = 0.0f;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0;; attempt++) {
         if ((rc = b_keys.alloc(capacity * 8)) || (rc = b_scores.alloc(capacity * 4))) return rc;
         a.capacity = capacity; a.keys = b_keys.as<u64>(); a.scores = b_scores.as<float>();
-        RK_HIP_TRY(hipMemset(b_cnt.p, 0, 3 * 8));
+        RK_HIP_TRY(hipMemset(b_cnt.p, 0, 4 * 8));
         RK_HIP_TRY(hipEventRecord(e0, 0));
-        if (n_tasks) hipLaunchKernelGGL(explore_kernel, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
+        if (n_tasks) {
+            // (a shorter in-register tail does not help wide alphabets: measured 32-34 Gvisits/s for INL = 1, 2, 3 on AA k=5)
+            int inl = 3;
+            if (const char *e = getenv("RK_BUILD_INLINE_LEVELS")) inl = atoi(e);  // developer knob
+            if (inl >= 3) hipLaunchKernelGGL(explore_kernel<3>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
+            else if (inl == 2) hipLaunchKernelGGL(explore_kernel<2>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
+            else hipLaunchKernelGGL(explore_kernel<1>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
+        }
         RK_HIP_TRY(hipGetLastError());
         RK_HIP_TRY(hipEventRecord(e1, 0));
         RK_HIP_TRY(hipEventSynchronize(e1));
         RK_HIP_TRY(hipEventElapsedTime(&explore_ms, e0, e1));
         RK_HIP_TRY(hipMemcpy(counters, b_cnt.p, sizeof(counters), hipMemcpyDeviceToHost));
         if (counters[1] <= capacity) break;
-        if (attempt == 1) return fail_msg(RK_ERR_HIP, "rk_build_db: tuple count changed between two identical launches");
-        capacity = counters[1];
+        // the hand-out of explorers to waves is dynamic, so the padding of a second run can differ a little: leave slack
+        if (attempt == 2) return fail_msg(RK_ERR_HIP, "rk_build_db: tuple buffer still too small after two resizes");
+        capacity = counters[1] + chunk_slack;
     }
-    const u64 n_tuples = counters[1];
+    const u64 n_slots = counters[1];  // chunks handed out: real tuples + TUPLE_PAD fillers, every slot written
+    const u64 n_tuples = counters[3];
     out->tuples = n_tuples;
     out->visits = counters[2];
     out->explore_ms = explore_ms;
-    if (n_tuples >= (1ull << 31)) return fail_msg(RK_ERR_UNSUPPORTED, "rk_build_db: %llu tuples in one call; split the nodes into batches", (unsigned long long)n_tuples);
+    if (n_slots >= (1ull << 31)) return fail_msg(RK_ERR_UNSUPPORTED, "rk_build_db: %llu tuples in one call; split the nodes into batches", (unsigned long long)n_tuples);
 
     // ---- stage 2: sort by (code, branch), max per key, run lengths per code ----
     RK_HIP_TRY(hipEventRecord(e1, 0));
@@ -322,16 +432,17 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     std::vector<u64> h_codes;
     std::vector<int> h_counts;
     if (n_tuples) {
-        const int n = (int)n_tuples;
+        const int n = (int)n_tuples;     // real tuples: the first n of the sorted slots (TUPLE_PAD fillers sort last)
+        const int n_sort = (int)n_slots;
         DevBuf b_keys2, b_scores2, b_tmp, b_nruns, b_codes, b_counts;
-        if ((rc = b_keys2.alloc((size_t)n * 8)) || (rc = b_scores2.alloc((size_t)n * 4)) || (rc = b_nruns.alloc(8))) return rc;
+        if ((rc = b_keys2.alloc((size_t)n_sort * 8)) || (rc = b_scores2.alloc((size_t)n_sort * 4)) || (rc = b_nruns.alloc(8))) return rc;
         hipcub::DoubleBuffer<u64> kb(b_keys.as<u64>(), b_keys2.as<u64>());
         hipcub::DoubleBuffer<float> vb(b_scores.as<float>(), b_scores2.as<float>());
         const int end_bit = (int)(16 + bits * d->k);
         size_t tmp_bytes = 0;
-        RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, n, 0, end_bit));
+        RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, n_sort, 0, end_bit));
         if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
-        RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, kb, vb, n, 0, end_bit));
+        RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, kb, vb, n_sort, 0, end_bit));
         u64 *sorted_k = kb.Current();
         float *sorted_v = vb.Current();
         u64 *uniq_k = kb.Alternate();
