@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -40,7 +41,7 @@ struct BuildArgs {
     u32 k, bits, n_nodes, n_sites, n_states, n_pos;  // n_pos = n_sites - k + 2 explorers per node
     u32 do_gap, limit1;
     float T;
-    u64 n_tasks;
+    u64 n_tasks, task_base;  // explorers of this launch: task_base .. task_base + n_tasks (node batches)
     u64 *task_counter;   // next explorer to hand out
     u64 *slot_counter;   // tuple-buffer slots handed out so far, in whole chunks (keeps counting past `capacity`)
     u64 *visit_counter;
@@ -185,8 +186,9 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
             } else if (t >= a.n_tasks) {
                 exhausted = true;
             } else {
-                const u32 node = (u32)(t / a.n_pos);
-                pos = (int)(t - (u64)node * a.n_pos);
+                const u64 tg = a.task_base + t;
+                const u32 node = (u32)(tg / a.n_pos);
+                pos = (int)(tg - (u64)node * a.n_pos);
                 node_base = (size_t)node * a.n_sites * a.n_states;
                 branch = a.node_branch[node];
                 sum = 0.0f; bound = false; boundK = -1; firstJump = -1; code = 0;
@@ -377,7 +379,7 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     a.gap_off = b_goff.as<u32>(); a.gap_len = b_glen.as<int>();
     a.k = d->k; a.bits = bits; a.n_nodes = d->n_nodes; a.n_sites = d->n_sites; a.n_states = d->n_states; a.n_pos = n_pos;
     a.do_gap = d->do_gap_jumps ? 1u : 0u; a.limit1 = d->limit_to_1_jump ? 1u : 0u;
-    a.T = d->thr_log10; a.n_tasks = n_tasks;
+    a.T = d->thr_log10; a.n_tasks = n_tasks; a.task_base = 0;
     a.task_counter = b_cnt.as<u64>(); a.slot_counter = a.task_counter + 1; a.visit_counter = a.task_counter + 2;
     a.tuple_counter = a.task_counter + 3;
 
@@ -385,79 +387,137 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     RK_HIP_TRY(hipEventCreate(&e0)); RK_HIP_TRY(hipEventCreate(&e1)); RK_HIP_TRY(hipEventCreate(&e2));
     struct EvGuard { hipEvent_t a, b, c; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evg{e0, e1, e2};
 
-    // ---- stage 1: explore; the tuple buffer is sized by a guess first and by the exact count if the guess was short ----
-    DevBuf b_keys, b_scores;
-    u64 capacity = n_tasks * 64 + (1u << 20);
-    if (capacity > (1ull << 28)) capacity = 1ull << 28;
-    u64 counters[4] = {0, 0, 0, 0};  // tasks, slots, visits, tuples
+    // ---- node batches: explore -> sort -> max per key, folded into the running set of unique (key, best score) pairs ----
+    // (one batch unless the tuple buffer of a single launch would pass ~2.7e8 slots: hipCUB counts items in 32 bits)
     const unsigned blocks = (unsigned)prop.multiProcessorCount * 3;  // persistent: 12 waves per CU (LDS: 10.5 KB per wave)
     const u64 chunk_slack = (u64)blocks * BUILD_WAVES_PER_BLOCK * TUPLE_CHUNK;  // every wave may leave one chunk half empty
-    capacity += chunk_slack;
-    float explore_ms = 0.0f;
-    for (int attempt = 0;; attempt++) {
-        if ((rc = b_keys.alloc(capacity * 8)) || (rc = b_scores.alloc(capacity * 4))) return rc;
-        a.capacity = capacity; a.keys = b_keys.as<u64>(); a.scores = b_scores.as<float>();
-        RK_HIP_TRY(hipMemset(b_cnt.p, 0, 4 * 8));
-        RK_HIP_TRY(hipEventRecord(e0, 0));
-        if (n_tasks) {
-            // (a shorter in-register tail does not help wide alphabets: measured 32-34 Gvisits/s for INL = 1, 2, 3 on AA k=5)
+    // slots one batch may fill: bounded by the 32-bit item counts of the sort and by device memory (12 bytes per slot, twice for
+    // the sort's double buffers, plus its scratch) -- with 288 GB of HBM that is normally the whole input in one batch
+    size_t mem_free = 0, mem_total = 0;
+    RK_HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
+    u64 target_slots = std::min<u64>((1ull << 31) - 2 - chunk_slack, (u64)mem_free / 40);
+    if (target_slots < (1u << 22)) return fail_msg(RK_ERR_NOMEM, "rk_build_db: only %zu bytes of device memory free", mem_free);
+    const int end_bit = (int)(16 + bits * d->k);
+    DevBuf run_keys, run_vals;  // running result
+    u64 run_n = 0;
+    u64 total_tuples = 0, total_visits = 0;
+    double explore_total = 0.0, reduce_total = 0.0;
+    u32 batch = d->n_nodes;
+    if (const char *e = getenv("RK_BUILD_BATCH_NODES")) batch = (u32)atoi(e);  // developer / test knob
+    if (batch < 1) batch = 1;
+    u32 node0 = 0;
+    double slots_per_task = -1.0;  // measured on the batches done so far (explorers register 0 .. thousands of words each)
+    const u64 generous = 4096;     // slots per explorer assumed while nothing has been measured
+    while (node0 < d->n_nodes && n_pos) {
+        u32 nb = std::min(batch, d->n_nodes - node0);
+        // nothing measured yet and too many explorers to size the buffer generously: measure on a small first batch
+        if (slots_per_task < 0 && (u64)nb * n_pos * generous > target_slots && !getenv("RK_BUILD_BATCH_NODES"))
+            nb = std::max<u32>(1, (u32)std::min<u64>(nb, target_slots / ((u64)n_pos * generous)));
+        a.task_base = (u64)node0 * n_pos;
+        a.n_tasks = (u64)nb * n_pos;
+        DevBuf b_keys, b_scores;
+        u64 capacity = slots_per_task < 0 ? a.n_tasks * generous : (u64)(slots_per_task * 1.3 * (double)a.n_tasks);
+        capacity = std::min<u64>(std::max<u64>(capacity, 1u << 20), target_slots > run_n ? target_slots - run_n : 1u << 20);
+        capacity += chunk_slack;
+        u64 counters[4] = {0, 0, 0, 0};  // tasks, slots, visits, tuples
+        float explore_ms = 0.0f;
+        for (int attempt = 0;; attempt++) {
+            // room for the running set behind the chunks: it is sorted together with the new tuples
+            if ((rc = b_keys.alloc((capacity + run_n) * 8)) || (rc = b_scores.alloc((capacity + run_n) * 4))) return rc;
+            a.capacity = capacity; a.keys = b_keys.as<u64>(); a.scores = b_scores.as<float>();
+            RK_HIP_TRY(hipMemset(b_cnt.p, 0, 4 * 8));
+            RK_HIP_TRY(hipEventRecord(e0, 0));
+            // (a shorter in-register tail does not help wide alphabets: measured 32-34 Gvisits/s for INL = 1, 2, 3 on AA k=5
+            //  before the chunked append, which is what that case was waiting for)
             int inl = 3;
             if (const char *e = getenv("RK_BUILD_INLINE_LEVELS")) inl = atoi(e);  // developer knob
             if (inl >= 3) hipLaunchKernelGGL(explore_kernel<3>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
             else if (inl == 2) hipLaunchKernelGGL(explore_kernel<2>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
             else hipLaunchKernelGGL(explore_kernel<1>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
+            RK_HIP_TRY(hipGetLastError());
+            RK_HIP_TRY(hipEventRecord(e1, 0));
+            RK_HIP_TRY(hipEventSynchronize(e1));
+            RK_HIP_TRY(hipEventElapsedTime(&explore_ms, e0, e1));
+            RK_HIP_TRY(hipMemcpy(counters, b_cnt.p, sizeof(counters), hipMemcpyDeviceToHost));
+            explore_total += explore_ms;
+            if (counters[1] <= capacity) break;
+            // the hand-out of explorers to waves is dynamic, so the padding of a second run can differ a little: leave slack
+            if (attempt == 2) return fail_msg(RK_ERR_HIP, "rk_build_db: tuple buffer still too small after two resizes");
+            capacity = counters[1] + chunk_slack;
+            if (capacity + run_n >= (1ull << 31) - 1) break;  // too many for one sort: handled below
         }
-        RK_HIP_TRY(hipGetLastError());
+        const u64 n_slots = counters[1];  // chunks handed out: real tuples + TUPLE_PAD fillers, every slot written
+        const u64 n_tuples = counters[3];
+        if (n_slots + run_n >= (1ull << 31) - 1 || n_slots > capacity) {
+            if (nb == 1) return fail_msg(RK_ERR_UNSUPPORTED, "rk_build_db: node %u alone registers %llu tuples on top of %llu database entries: more than one sort can take", node0, (unsigned long long)n_tuples, (unsigned long long)run_n);
+            batch = nb / 2;  // redo this range in smaller pieces
+            continue;
+        }
+        total_tuples += n_tuples;
+        total_visits += counters[2];
+        // ---- sort by (code, branch), max per key ----
         RK_HIP_TRY(hipEventRecord(e1, 0));
-        RK_HIP_TRY(hipEventSynchronize(e1));
-        RK_HIP_TRY(hipEventElapsedTime(&explore_ms, e0, e1));
-        RK_HIP_TRY(hipMemcpy(counters, b_cnt.p, sizeof(counters), hipMemcpyDeviceToHost));
-        if (counters[1] <= capacity) break;
-        // the hand-out of explorers to waves is dynamic, so the padding of a second run can differ a little: leave slack
-        if (attempt == 2) return fail_msg(RK_ERR_HIP, "rk_build_db: tuple buffer still too small after two resizes");
-        capacity = counters[1] + chunk_slack;
+        if (n_tuples + run_n) {
+            if (run_n) {  // the running set goes behind the chunks; TUPLE_PAD fillers still sort last
+                RK_HIP_TRY(hipMemcpyAsync(b_keys.as<u64>() + n_slots, run_keys.p, run_n * 8, hipMemcpyDeviceToDevice, 0));
+                RK_HIP_TRY(hipMemcpyAsync(b_scores.as<float>() + n_slots, run_vals.p, run_n * 4, hipMemcpyDeviceToDevice, 0));
+            }
+            const int n_sort = (int)(n_slots + run_n);
+            const int n = (int)(n_tuples + run_n);  // real pairs: the first n of the sorted slots
+            DevBuf b_keys2, b_scores2, b_tmp, b_nruns;
+            if ((rc = b_keys2.alloc((size_t)n_sort * 8)) || (rc = b_scores2.alloc((size_t)n_sort * 4)) || (rc = b_nruns.alloc(8))) return rc;
+            hipcub::DoubleBuffer<u64> kb(b_keys.as<u64>(), b_keys2.as<u64>());
+            hipcub::DoubleBuffer<float> vb(b_scores.as<float>(), b_scores2.as<float>());
+            size_t tmp_bytes = 0;
+            RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, n_sort, 0, end_bit));
+            if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
+            RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, kb, vb, n_sort, 0, end_bit));
+            u64 *sorted_k = kb.Current();
+            float *sorted_v = vb.Current();
+            u64 *uniq_k = kb.Alternate();
+            float *max_v = vb.Alternate();
+            tmp_bytes = 0;
+            RK_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_bytes, sorted_k, uniq_k, sorted_v, max_v, b_nruns.as<int>(), hipcub::Max(), n));
+            if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
+            RK_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(b_tmp.p, tmp_bytes, sorted_k, uniq_k, sorted_v, max_v, b_nruns.as<int>(), hipcub::Max(), n));
+            int runs = 0;
+            RK_HIP_TRY(hipMemcpy(&runs, b_nruns.p, 4, hipMemcpyDeviceToHost));
+            if ((rc = run_keys.alloc((size_t)runs * 8)) || (rc = run_vals.alloc((size_t)runs * 4))) return rc;
+            RK_HIP_TRY(hipMemcpy(run_keys.p, uniq_k, (size_t)runs * 8, hipMemcpyDeviceToDevice));
+            RK_HIP_TRY(hipMemcpy(run_vals.p, max_v, (size_t)runs * 4, hipMemcpyDeviceToDevice));
+            run_n = (u64)runs;
+        }
+        RK_HIP_TRY(hipEventRecord(e2, 0));
+        RK_HIP_TRY(hipEventSynchronize(e2));
+        float ms = 0.0f;
+        RK_HIP_TRY(hipEventElapsedTime(&ms, e1, e2));
+        reduce_total += ms;
+        // next batch: aim at target_slots from what this one produced per node
+        slots_per_task = std::max(1.0, (double)n_slots / (double)a.n_tasks);
+        if (!getenv("RK_BUILD_BATCH_NODES")) {
+            const u64 per_node = std::max<u64>(1, n_slots / nb);
+            const u64 want = std::max<u64>(1, target_slots / per_node);
+            batch = (u32)std::min<u64>(want, d->n_nodes);
+        }
+        node0 += nb;
     }
-    const u64 n_slots = counters[1];  // chunks handed out: real tuples + TUPLE_PAD fillers, every slot written
-    const u64 n_tuples = counters[3];
-    out->tuples = n_tuples;
-    out->visits = counters[2];
-    out->explore_ms = explore_ms;
-    if (n_slots >= (1ull << 31)) return fail_msg(RK_ERR_UNSUPPORTED, "rk_build_db: %llu tuples in one call; split the nodes into batches", (unsigned long long)n_tuples);
+    out->tuples = total_tuples;
+    out->visits = total_visits;
+    out->explore_ms = explore_total;
 
-    // ---- stage 2: sort by (code, branch), max per key, run lengths per code ----
-    RK_HIP_TRY(hipEventRecord(e1, 0));
-    u64 n_entries = 0, n_keys = 0;
+    // ---- run lengths of the codes over the unique (code, branch) keys -> CSR ----
+    u64 n_entries = run_n, n_keys = 0;
     std::vector<u64> h_keys_unique;
     std::vector<float> h_scores;
     std::vector<u64> h_codes;
     std::vector<int> h_counts;
-    if (n_tuples) {
-        const int n = (int)n_tuples;     // real tuples: the first n of the sorted slots (TUPLE_PAD fillers sort last)
-        const int n_sort = (int)n_slots;
-        DevBuf b_keys2, b_scores2, b_tmp, b_nruns, b_codes, b_counts;
-        if ((rc = b_keys2.alloc((size_t)n_sort * 8)) || (rc = b_scores2.alloc((size_t)n_sort * 4)) || (rc = b_nruns.alloc(8))) return rc;
-        hipcub::DoubleBuffer<u64> kb(b_keys.as<u64>(), b_keys2.as<u64>());
-        hipcub::DoubleBuffer<float> vb(b_scores.as<float>(), b_scores2.as<float>());
-        const int end_bit = (int)(16 + bits * d->k);
+    if (run_n) {
+        RK_HIP_TRY(hipEventRecord(e1, 0));
+        const int runs = (int)run_n;
+        DevBuf b_tmp, b_nruns, b_codes, b_counts;
+        if ((rc = b_codes.alloc((size_t)runs * 8)) || (rc = b_counts.alloc((size_t)runs * 4)) || (rc = b_nruns.alloc(8))) return rc;
+        hipcub::TransformInputIterator<u64, ShiftRight16, u64 *> code_it(run_keys.as<u64>(), ShiftRight16());
         size_t tmp_bytes = 0;
-        RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, n_sort, 0, end_bit));
-        if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
-        RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, kb, vb, n_sort, 0, end_bit));
-        u64 *sorted_k = kb.Current();
-        float *sorted_v = vb.Current();
-        u64 *uniq_k = kb.Alternate();
-        float *max_v = vb.Alternate();
-        tmp_bytes = 0;
-        RK_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_bytes, sorted_k, uniq_k, sorted_v, max_v, b_nruns.as<int>(), hipcub::Max(), n));
-        if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
-        RK_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(b_tmp.p, tmp_bytes, sorted_k, uniq_k, sorted_v, max_v, b_nruns.as<int>(), hipcub::Max(), n));
-        int runs = 0;
-        RK_HIP_TRY(hipMemcpy(&runs, b_nruns.p, 4, hipMemcpyDeviceToHost));
-        n_entries = (u64)runs;
-        // run lengths of the codes over the unique (code, branch) keys
-        if ((rc = b_codes.alloc((size_t)runs * 8)) || (rc = b_counts.alloc((size_t)runs * 4))) return rc;
-        hipcub::TransformInputIterator<u64, ShiftRight16, u64 *> code_it(uniq_k, ShiftRight16());
-        tmp_bytes = 0;
         RK_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_bytes, code_it, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), runs));
         if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
         RK_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(b_tmp.p, tmp_bytes, code_it, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), runs));
@@ -468,13 +528,14 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
         RK_HIP_TRY(hipEventSynchronize(e2));
         float ms = 0.0f;
         RK_HIP_TRY(hipEventElapsedTime(&ms, e1, e2));
-        out->reduce_ms = ms;
+        reduce_total += ms;
         h_keys_unique.resize(n_entries); h_scores.resize(n_entries); h_codes.resize(n_keys); h_counts.resize(n_keys);
-        RK_HIP_TRY(hipMemcpy(h_keys_unique.data(), uniq_k, n_entries * 8, hipMemcpyDeviceToHost));
-        RK_HIP_TRY(hipMemcpy(h_scores.data(), max_v, n_entries * 4, hipMemcpyDeviceToHost));
+        RK_HIP_TRY(hipMemcpy(h_keys_unique.data(), run_keys.p, n_entries * 8, hipMemcpyDeviceToHost));
+        RK_HIP_TRY(hipMemcpy(h_scores.data(), run_vals.p, n_entries * 4, hipMemcpyDeviceToHost));
         RK_HIP_TRY(hipMemcpy(h_codes.data(), b_codes.p, n_keys * 8, hipMemcpyDeviceToHost));
         RK_HIP_TRY(hipMemcpy(h_counts.data(), b_counts.p, n_keys * 4, hipMemcpyDeviceToHost));
     }
+    out->reduce_ms = reduce_total;
     out->n_keys = n_keys;
     out->n_entries = n_entries;
     out->key_codes = (uint64_t *)malloc((n_keys + 1) * 8);

@@ -100,3 +100,15 @@ def test_built_db_places_reads_drawn_from_its_own_posteriors():
     hit = (got.branch[:, 0] == np.array(truth)).mean()
     assert hit > 0.95, hit
     db.close()
+
+
+def test_node_batches_fold_into_the_same_database(monkeypatch):
+    """Large inputs are explored in node batches whose reduced (k-mer, branch) -> best score sets are merged; forcing tiny
+    batches must give the identical database."""
+    states, pp, nb = synth.make_pp_tables(4, 14, 90, seed=9, n_branches=5)  # several nodes per branch: maxima across batches
+    _, T = synth.thresholds(1.5, 4, 6)
+    monkeypatch.setenv("RK_BUILD_BATCH_NODES", "3")
+    got, ref = _check(4, 6, states, pp, nb, T)
+    monkeypatch.delenv("RK_BUILD_BATCH_NODES")
+    one = ra.build_db(4, 6, states, pp, nb, T)
+    assert np.array_equal(one.scores.view(np.uint32), got.scores.view(np.uint32)) and one.tuples == got.tuples
