@@ -290,6 +290,11 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
     if (lane == 0 && tuples) atomicAdd(a.tuple_counter, tuples);
 }
 
+__global__ void split_keys_kernel(const u64 *keys, u64 n, unsigned short *branch) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        branch[i] = (unsigned short)(keys[i] & 0xFFFFu);
+}
+
 struct ShiftRight16 {
     __host__ __device__ __forceinline__ u64 operator()(const u64 &k) const { return k >> 16; }
 };
@@ -505,22 +510,27 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     out->visits = total_visits;
     out->explore_ms = explore_total;
 
-    // ---- run lengths of the codes over the unique (code, branch) keys -> CSR ----
-    u64 n_entries = run_n, n_keys = 0;
-    std::vector<u64> h_keys_unique;
-    std::vector<float> h_scores;
-    std::vector<u64> h_codes;
+    // ---- run lengths of the codes over the unique (code, branch) keys -> CSR, straight into the caller's arrays ----
+    const u64 n_entries = run_n;
+    out->n_entries = n_entries;
+    out->branch_ids = (uint16_t *)malloc((n_entries + 1) * 2);
+    out->scores = (float *)malloc((n_entries + 1) * 4);
+    if (!out->branch_ids || !out->scores) { rk_built_free(out); return fail_msg(RK_ERR_NOMEM, "rk_build_db: host OOM for %llu entries", (unsigned long long)n_entries); }
+    u64 n_keys = 0;
     std::vector<int> h_counts;
     if (run_n) {
         RK_HIP_TRY(hipEventRecord(e1, 0));
         const int runs = (int)run_n;
-        DevBuf b_tmp, b_nruns, b_codes, b_counts;
-        if ((rc = b_codes.alloc((size_t)runs * 8)) || (rc = b_counts.alloc((size_t)runs * 4)) || (rc = b_nruns.alloc(8))) return rc;
+        DevBuf b_tmp, b_nruns, b_codes, b_counts, b_branch;
+        if ((rc = b_codes.alloc((size_t)runs * 8)) || (rc = b_counts.alloc((size_t)runs * 4)) || (rc = b_nruns.alloc(8)) ||
+            (rc = b_branch.alloc((size_t)runs * 2))) { rk_built_free(out); return rc; }
         hipcub::TransformInputIterator<u64, ShiftRight16, u64 *> code_it(run_keys.as<u64>(), ShiftRight16());
         size_t tmp_bytes = 0;
         RK_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_bytes, code_it, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), runs));
-        if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
+        if ((rc = b_tmp.alloc(tmp_bytes))) { rk_built_free(out); return rc; }
         RK_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(b_tmp.p, tmp_bytes, code_it, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), runs));
+        hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)prop.multiProcessorCount * 8), dim3(256), 0, 0, run_keys.as<u64>(), run_n, b_branch.as<unsigned short>());
+        RK_HIP_TRY(hipGetLastError());
         int nk = 0;
         RK_HIP_TRY(hipMemcpy(&nk, b_nruns.p, 4, hipMemcpyDeviceToHost));
         n_keys = (u64)nk;
@@ -529,33 +539,26 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
         float ms = 0.0f;
         RK_HIP_TRY(hipEventElapsedTime(&ms, e1, e2));
         reduce_total += ms;
-        h_keys_unique.resize(n_entries); h_scores.resize(n_entries); h_codes.resize(n_keys); h_counts.resize(n_keys);
-        RK_HIP_TRY(hipMemcpy(h_keys_unique.data(), run_keys.p, n_entries * 8, hipMemcpyDeviceToHost));
-        RK_HIP_TRY(hipMemcpy(h_scores.data(), run_vals.p, n_entries * 4, hipMemcpyDeviceToHost));
-        RK_HIP_TRY(hipMemcpy(h_codes.data(), b_codes.p, n_keys * 8, hipMemcpyDeviceToHost));
+        out->key_codes = (uint64_t *)malloc((n_keys + 1) * 8);
+        out->row_offsets = (uint64_t *)malloc((n_keys + 1) * 8);
+        if (!out->key_codes || !out->row_offsets) { rk_built_free(out); return fail_msg(RK_ERR_NOMEM, "rk_build_db: host OOM for %llu keys", (unsigned long long)n_keys); }
+        h_counts.resize(n_keys);
+        RK_HIP_TRY(hipMemcpy(out->key_codes, b_codes.p, n_keys * 8, hipMemcpyDeviceToHost));
         RK_HIP_TRY(hipMemcpy(h_counts.data(), b_counts.p, n_keys * 4, hipMemcpyDeviceToHost));
+        RK_HIP_TRY(hipMemcpy(out->branch_ids, b_branch.p, n_entries * 2, hipMemcpyDeviceToHost));
+        RK_HIP_TRY(hipMemcpy(out->scores, run_vals.p, n_entries * 4, hipMemcpyDeviceToHost));
+    } else {
+        out->key_codes = (uint64_t *)malloc(8);
+        out->row_offsets = (uint64_t *)malloc(8);
+        if (!out->key_codes || !out->row_offsets) { rk_built_free(out); return fail_msg(RK_ERR_NOMEM, "rk_build_db: host OOM"); }
     }
     out->reduce_ms = reduce_total;
     out->n_keys = n_keys;
-    out->n_entries = n_entries;
-    out->key_codes = (uint64_t *)malloc((n_keys + 1) * 8);
-    out->row_offsets = (uint64_t *)malloc((n_keys + 1) * 8);
-    out->branch_ids = (uint16_t *)malloc((n_entries + 1) * 2);
-    out->scores = (float *)malloc((n_entries + 1) * 4);
-    if (!out->key_codes || !out->row_offsets || !out->branch_ids || !out->scores) {
-        rk_built_free(out);
-        return fail_msg(RK_ERR_NOMEM, "rk_build_db: host OOM for %llu entries", (unsigned long long)n_entries);
-    }
     u64 acc = 0;
     for (u64 i = 0; i < n_keys; i++) {
-        out->key_codes[i] = h_codes[i];
         out->row_offsets[i] = acc;
         acc += (u64)h_counts[i];
     }
     out->row_offsets[n_keys] = acc;
-    for (u64 i = 0; i < n_entries; i++) {
-        out->branch_ids[i] = (uint16_t)(h_keys_unique[i] & 0xFFFF);
-        out->scores[i] = h_scores[i];
-    }
     return RK_OK;
 }
