@@ -61,3 +61,34 @@ def test_fasta_to_jplace_matches_oracle(tmp_path, n_nodes, amb):
             assert row[0] == node.jplace_edge
             assert np.float32(row[3]) == node.bl / np.float32(2)
     assert names[3] == ["read3 sample=x/3", "dup3"]
+
+
+def test_build_tool_then_place_tool(tmp_path):
+    """posterior tables -> tools.build (GPU) -> --jsondb file -> tools.place (GPU) -> jplace: reads drawn from a node's most
+    likely states come back on that node's branch."""
+    from rappas_amd.tools import build as build_tool
+    n_nodes, L, k = 21, 300, 8
+    nwk = synth.make_newick(n_nodes, seed=2)
+    states, pp, _ = synth.make_pp_tables(4, n_nodes, L, seed=31, peaked=0.97)
+    nb = np.arange(n_nodes, dtype=np.uint16)
+    np.savez(tmp_path / "pp.npz", states=states, pp_log10=pp, node_branch=nb)
+    (tmp_path / "tree.nwk").write_text(nwk)
+    assert build_tool.main(["--pp", str(tmp_path / "pp.npz"), "--tree", str(tmp_path / "tree.nwk"), "-k", str(k),
+                            "--out", str(tmp_path / "db.json")]) == 0
+    rng = np.random.default_rng(8)
+    letters = np.frombuffer(b"ATCG", np.uint8)
+    lines, truth = [], []
+    for i in range(60):
+        node = int(rng.integers(0, n_nodes))
+        s = int(rng.integers(0, L - 120))
+        lines += [f">q{i}", letters[states[node, s:s + 120, 0]].tobytes().decode()]
+        truth.append(node)
+    (tmp_path / "q.fasta").write_text("\n".join(lines) + "\n")
+    assert place_tool.main(["--jsondb", str(tmp_path / "db.json"), "--fasta", str(tmp_path / "q.fasta"),
+                            "--out", str(tmp_path / "q.jplace")]) == 0
+    js = json.loads((tmp_path / "q.jplace").read_text())
+    tree = hostio.parse_newick(nwk)
+    edge_of = {n.id: n.jplace_edge for n in tree.nodes}
+    by_name = {p["nm"][0][0]: p["p"][0][0] for p in js["placements"]}
+    hits = sum(by_name.get(f"q{i}") == edge_of[truth[i]] for i in range(60))
+    assert hits >= 57, hits
