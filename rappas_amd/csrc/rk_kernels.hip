@@ -288,14 +288,6 @@ __device__ __forceinline__ void apply_slot(u32 *S, u32 sb, float sc, float QT, f
     const float nw = base + d;
     *p = __float_as_uint(nw);
 }
-__device__ __forceinline__ void apply_entry_masked(u32 *S, u32 br, float sc, float QT, float T) {
-    u32 old = S[br];
-    float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
-    float d = sc - T;
-    float nw = base + d;
-    S[br] = __float_as_uint(nw);
-}
-
 template <int G, int U, bool WIDE, bool SOA = false>
 __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list, int cnt, u32 li,
                                                 const unsigned char *rows, float QT, float T) {
@@ -319,9 +311,10 @@ __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list,
 }
 
 // ------------------------------------------------------------------------------------------------
-// accumulate, fast form: the hit list holds one item per CHUNK (<= G entries of one row, whole 64-byte lines),
-// written in k-mer order by the probe phase.  A step is then: decode one item, one entry load per lane, one LDS
-// read-modify-write -- no row cursor.  Items are 32-bit when the row blob is < 4 GiB:
+// accumulate by chunks, general form (any group width, any blob size; G == 16 with 32-bit offsets takes
+// accumulate_chunks16 below instead): the hit list holds one item per CHUNK (<= G entries of one row, whole 64-byte
+// lines), written in k-mer order by the probe phase.  A step is then: decode one item, one entry load per lane, one
+// LDS read-modify-write -- no row cursor.  Items are 32-bit when the row blob is < 4 GiB:
 //   (64-byte line index of the chunk) << 4 | (lines in the chunk),   else the 64-bit descriptor format.
 // Items are read one ring-iteration ahead so their LDS latency is hidden; the list region has 3U slots of slack.
 // ------------------------------------------------------------------------------------------------
@@ -574,20 +567,7 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, 
     return num;
 }
 
-// group-wide maxima of a 32-bit value.  G == 16: a group is one DPP row, four rotate-and-max steps, no LDS traffic.
-template <int G>
-__device__ __forceinline__ float group_max_f32(float v) {
-    if (G == 16) {
-        v = fmaxf(v, __uint_as_float(row_ror32<8>(__float_as_uint(v))));
-        v = fmaxf(v, __uint_as_float(row_ror32<4>(__float_as_uint(v))));
-        v = fmaxf(v, __uint_as_float(row_ror32<2>(__float_as_uint(v))));
-        v = fmaxf(v, __uint_as_float(row_ror32<1>(__float_as_uint(v))));
-    } else {
-#pragma unroll
-        for (int s = 1; s < G; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, G));
-    }
-    return v;
-}
+// group-wide maximum of a 32-bit value.  G == 16: a group is one DPP row, four rotate-and-max steps, no LDS traffic.
 template <int G>
 __device__ __forceinline__ u32 group_max_u32(u32 v) {
     if (G == 16) {
