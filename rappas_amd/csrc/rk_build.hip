@@ -144,9 +144,57 @@ __device__ __forceinline__ void explore_tail(const BuildArgs &a, volatile WaveCu
     }
 }
 
+// Four-state alphabets (DNA): the rows of the INL + 1 sites a tail touches are loaded once at its entry (one float4 of
+// posteriors and one packed word of states per site) and every visit below reads registers -- no load, no load latency, per
+// visit.  Same statements as explore_tail; `TOP - L` is the level of the node inside the tail, a compile-time register index.
+struct Sites4 {
+    float4 p[4];
+    u32 st[4];
+};
+__device__ __forceinline__ float pick4(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
+
+template <int TOP, int L>
+__device__ __forceinline__ void explore_tail4(const BuildArgs &a, volatile WaveCursor *wc, Explorer &e, const Sites4 &t,
+                                              int site, int rank, int depth, u32 branch, u32 lane) {
+    if (site > (int)a.n_sites - 1) return;                                  // :109-111
+    const u32 st = (t.st[TOP - L] >> (8 * rank)) & 0xFFu;
+    const float p = pick4(t.p[TOP - L], rank);
+    e.visits++;
+    const u32 sh = 2u * (u32)depth;
+    e.code = (e.code & ~(3ull << sh)) | ((u64)st << sh);                    // :117
+    e.sum = (float)((double)e.sum + (double)p);                             // :119
+    e.bound = e.sum < a.T;                                                  // :120
+    if (e.bound) e.boundK = depth;                                          // :121-123
+    if (L == 0) {
+        append_tuples(a, wc, !e.bound, (e.code << 16) | branch, e.sum, lane, e.tuples);  // :128-138
+        e.sum = (float)((double)e.sum - (double)p);                         // :141
+        return;
+    } else {
+        for (int j2 = 0; j2 < 4; j2++) {                                    // :147
+            if (e.bound && e.boundK == depth + 1) break;                    // :148-150
+            explore_tail4<TOP, (L > 0 ? L - 1 : 0)>(a, wc, e, t, site + 1, j2, depth + 1, branch, lane);
+        }
+        e.sum = (float)((double)e.sum - (double)p);                         // :198
+    }
+}
+
+template <int TOP>
+__device__ __forceinline__ void run_tail4(const BuildArgs &a, volatile WaveCursor *wc, Explorer &e, int site, int rank, int depth,
+                                          size_t node_base, u32 branch, u32 lane) {
+    Sites4 t;
+#pragma unroll
+    for (int l = 0; l <= TOP; l++) {
+        const int sl = min(site + l, (int)a.n_sites - 1);  // rows beyond the alignment are never read back (:109-111)
+        const size_t at = node_base + (size_t)sl * 4;
+        t.p[l] = *(const float4 *)(a.pp + at);
+        t.st[l] = *(const u32 *)(a.states + at);
+    }
+    explore_tail4<TOP, TOP>(a, wc, e, t, site, rank, depth, branch, lane);
+}
+
 // INL = levels of the recursion below a node that explore_tail runs in registers (the node itself included: 1 + NS + ... +
 // NS^INL visits per transition).
-template <int INL>
+template <int INL, bool V4>
 __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(BuildArgs a) {
     __shared__ Frames frames[BUILD_WAVES_PER_BLOCK];
     __shared__ WaveCursor cursors[BUILD_WAVES_PER_BLOCK];
@@ -248,12 +296,22 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
         if (call && !a.do_gap && below <= INL) {
             if (cd == 0) firstJump = -1;
             Explorer e{sum, bound, boundK, code, visits, tuples};
-            switch (below) {
-            case 0: explore_tail<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-            case 1: explore_tail<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-            case 2: if (INL >= 2) explore_tail<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-            case 3: if (INL >= 3) explore_tail<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-            default: break;
+            if (V4) {
+                switch (below) {
+                case 0: run_tail4<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 1: run_tail4<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 2: if (INL >= 2) run_tail4<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 3: if (INL >= 3) run_tail4<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                default: break;
+                }
+            } else {
+                switch (below) {
+                case 0: explore_tail<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 1: explore_tail<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 2: if (INL >= 2) explore_tail<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 3: if (INL >= 3) explore_tail<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                default: break;
+                }
             }
             sum = e.sum; bound = e.bound; boundK = e.boundK; code = e.code; visits = e.visits; tuples = e.tuples;
         } else if (call && ci <= S - 1) {  // :109-111
@@ -436,9 +494,11 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
             //  before the chunked append, which is what that case was waiting for)
             int inl = 3;
             if (const char *e = getenv("RK_BUILD_INLINE_LEVELS")) inl = atoi(e);  // developer knob
-            if (inl >= 3) hipLaunchKernelGGL(explore_kernel<3>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
-            else if (inl == 2) hipLaunchKernelGGL(explore_kernel<2>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
-            else hipLaunchKernelGGL(explore_kernel<1>, dim3(blocks), dim3(64 * BUILD_WAVES_PER_BLOCK), 0, 0, a);
+            const dim3 grid(blocks), block(64 * BUILD_WAVES_PER_BLOCK);
+            const bool v4 = d->n_states == 4 && !getenv("RK_BUILD_NO_V4");  // whole site rows in registers (DNA)
+            if (inl >= 3) { if (v4) hipLaunchKernelGGL((explore_kernel<3, true>), grid, block, 0, 0, a); else hipLaunchKernelGGL((explore_kernel<3, false>), grid, block, 0, 0, a); }
+            else if (inl == 2) { if (v4) hipLaunchKernelGGL((explore_kernel<2, true>), grid, block, 0, 0, a); else hipLaunchKernelGGL((explore_kernel<2, false>), grid, block, 0, 0, a); }
+            else { if (v4) hipLaunchKernelGGL((explore_kernel<1, true>), grid, block, 0, 0, a); else hipLaunchKernelGGL((explore_kernel<1, false>), grid, block, 0, 0, a); }
             RK_HIP_TRY(hipGetLastError());
             RK_HIP_TRY(hipEventRecord(e1, 0));
             RK_HIP_TRY(hipEventSynchronize(e1));
