@@ -59,3 +59,26 @@ def has_tie(e):
     """exact score tie among the touched branches of a golden read (tie order is layout-dependent in the reference)."""
     vals = sorted(e["S"].values())
     return any(a == b for a, b in zip(vals, vals[1:]))
+
+
+def build_cases():
+    return sorted(glob.glob(os.path.join(HERE, "golden", "build", "*.json")))
+
+
+def load_build(path):
+    """tests/golden/build/*.json (make_golden_build.py) -> kwargs for the builders + expected CSR."""
+    with open(path) as f:
+        g = json.load(f)
+    states = np.array(g["states"], np.uint8)
+    pp = np.array(g["pp_bits"], np.uint32).view(np.float32)
+    kw = {}
+    if g["gaps"] is not None:
+        off = np.zeros(len(g["gaps"]) + 1, np.uint32)
+        off[1:] = np.cumsum([len(x) for x in g["gaps"]])
+        kw = dict(gap_off=off, gap_len=np.array([v for x in g["gaps"] for v in x], np.int32), limit_to_1_jump=g["limit_to_1_jump"])
+    T = np.array([g["T_bits"]], np.uint32).view(np.float32)[0]
+    e = g["expected"]
+    exp = dict(key_codes=np.array(e["key_codes"], np.uint64), row_offsets=np.array(e["row_offsets"], np.uint64),
+               branch_ids=np.array(e["branch_ids"], np.uint16), score_bits=np.array(e["score_bits"], np.uint32),
+               tuples=e["tuples"], visits=e["visits"])
+    return (g["alphabet"], g["k"], states, pp, np.array(g["node_branch"], np.uint16), T), kw, exp

@@ -112,3 +112,16 @@ def test_node_batches_fold_into_the_same_database(monkeypatch):
     monkeypatch.delenv("RK_BUILD_BATCH_NODES")
     one = ra.build_db(4, 6, states, pp, nb, T)
     assert np.array_equal(one.scores.view(np.uint32), got.scores.view(np.uint32)) and one.tuples == got.tuples
+
+
+from tests import golden_util as GU  # noqa: E402
+
+
+@pytest.mark.parametrize("path", GU.build_cases(), ids=lambda p: p.split("/")[-1][:-5])
+def test_build_matches_committed_vectors(path):
+    args, kw, exp = GU.load_build(path)
+    got = ra.build_db(*args, **kw)
+    assert np.array_equal(got.key_codes, exp["key_codes"]) and np.array_equal(got.row_offsets, exp["row_offsets"])
+    assert np.array_equal(got.branch_ids, exp["branch_ids"])
+    assert np.array_equal(got.scores.view(np.uint32), exp["score_bits"])
+    assert got.tuples == exp["tuples"] and got.visits == exp["visits"]

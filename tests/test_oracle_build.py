@@ -108,3 +108,20 @@ def test_gap_jumps(limit1):
 def test_trailing_gap_run_is_not_an_interval():
     off, lens = synth.gap_intervals(["ACGT--", "AC-T-A"])
     assert _lists(off, lens) == [[], [], [1], [], [1], []]
+
+
+from tests import golden_util as GU  # noqa: E402
+
+
+@pytest.mark.parametrize("path", GU.build_cases(), ids=lambda p: p.split("/")[-1][:-5])
+def test_oracle_matches_committed_vectors(path):
+    args, kw, exp = GU.load_build(path)
+    got = O.build_db(*args, **kw)
+    assert np.array_equal(got["key_codes"], exp["key_codes"]) and np.array_equal(got["row_offsets"], exp["row_offsets"])
+    assert np.array_equal(got["branch_ids"], exp["branch_ids"])
+    assert np.array_equal(got["scores"].view(np.uint32), exp["score_bits"])
+    assert got["tuples"] == exp["tuples"] and got["visits"] == exp["visits"]
+
+
+def test_committed_vectors_exist():
+    assert len(GU.build_cases()) >= 5
