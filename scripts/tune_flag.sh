@@ -1,9 +1,6 @@
 #!/bin/bash
-# usage: scripts/tune_flag.sh "<-Dflags A>" "<-Dflags B>" ... ; builds one variant per argument and benches it
+# Timing of one-off compile-time variants of the placement kernel: FLAGS="-DX=1" scripts/tune_flag.sh [bench args]
 cd "$(dirname "$0")/.."
-i=0
-for f in "$@"; do
-  i=$((i+1))
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off $f -o /tmp/librk_flag_$i.so rappas_amd/csrc/rk_engine.hip || exit 1
-  RK_LIB=/tmp/librk_flag_$i.so timeout -k 5 120 python bench.py --steps 5 --warmup 1 --verify 2000 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$f]', round(d['roofline']['kernel_ms'],2), 'ms', round(d['value']/1e6,1), 'Mreads/s')"
-done
+tag=$(echo "$FLAGS" | tr -c 'A-Za-z0-9' '_')
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off $FLAGS -o /tmp/librk_flag_$tag.so rappas_amd/csrc/rk_engine.hip || exit 1
+RK_LIB=/tmp/librk_flag_$tag.so timeout -k 5 120 python bench.py --steps 5 --warmup 1 --verify 2000 --no-cpu-baseline "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('flags=$FLAGS', round(d['roofline']['kernel_ms'],2), 'ms', round(d['value']/1e6,1), 'Mreads/s')"
