@@ -192,9 +192,79 @@ __device__ __forceinline__ void run_tail4(const BuildArgs &a, volatile WaveCurso
     explore_tail4<TOP, TOP>(a, wc, e, t, site, rank, depth, branch, lane);
 }
 
+// Twenty-state alphabets (amino acids): 95 % of the visits of a tail are its leaves, which all sit on ONE site; that site's row
+// (20 posteriors + 20 packed states) is loaded once at the tail's entry and the leaf loop, fully unrolled, reads registers.
+// The 1 + 20 + 400 nodes above the leaves load per visit as in explore_tail.
+struct Row20 {
+    float p[20];
+    u32 st[5];
+};
+
+template <int L>
+__device__ __forceinline__ void explore_tail20(const BuildArgs &a, volatile WaveCursor *wc, Explorer &e, const Row20 &leaf,
+                                               int site, int rank, int depth, size_t node_base, u32 branch, u32 lane) {
+    if (site > (int)a.n_sites - 1) return;                                  // :109-111
+    u32 st;
+    float p;
+    if (L == 0) {
+        st = (leaf.st[rank >> 2] >> (8 * (rank & 3))) & 0xFFu;              // rank is a constant here (unrolled caller)
+        p = leaf.p[rank];
+    } else {
+        const size_t at = node_base + (size_t)site * 20 + (size_t)rank;
+        st = a.states[at];
+        p = a.pp[at];
+    }
+    e.visits++;
+    const u32 sh = 5u * (u32)depth;
+    e.code = (e.code & ~(31ull << sh)) | ((u64)st << sh);                   // :117
+    e.sum = (float)((double)e.sum + (double)p);                             // :119
+    e.bound = e.sum < a.T;                                                  // :120
+    if (e.bound) e.boundK = depth;                                          // :121-123
+    if (L == 0) {
+        append_tuples(a, wc, !e.bound, (e.code << 16) | branch, e.sum, lane, e.tuples);  // :128-138
+        e.sum = (float)((double)e.sum - (double)p);                         // :141
+        return;
+    } else if (L == 1) {
+#pragma unroll
+        for (int j2 = 0; j2 < 20; j2++) {                                   // :147, unrolled: leaf.p[j2] is a register
+            if (e.bound && e.boundK == depth + 1) break;                    // :148-150
+            explore_tail20<0>(a, wc, e, leaf, site + 1, j2, depth + 1, node_base, branch, lane);
+        }
+        e.sum = (float)((double)e.sum - (double)p);                         // :198
+    } else {
+        for (int j2 = 0; j2 < 20; j2++) {
+            if (e.bound && e.boundK == depth + 1) break;
+            explore_tail20<(L > 1 ? L - 1 : 1)>(a, wc, e, leaf, site + 1, j2, depth + 1, node_base, branch, lane);
+        }
+        e.sum = (float)((double)e.sum - (double)p);
+    }
+}
+
+template <int TOP>
+__device__ __forceinline__ void run_tail20(const BuildArgs &a, volatile WaveCursor *wc, Explorer &e, int site, int rank, int depth,
+                                           size_t node_base, u32 branch, u32 lane) {
+    Row20 leaf;
+    const int sl = min(site + TOP, (int)a.n_sites - 1);  // a leaf site beyond the alignment is never read back (:109-111)
+    const size_t at = node_base + (size_t)sl * 20;
+    const float4 *pv = (const float4 *)(a.pp + at);
+    const u32 *sv = (const u32 *)(a.states + at);
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const float4 v = pv[q];
+        leaf.p[4 * q] = v.x; leaf.p[4 * q + 1] = v.y; leaf.p[4 * q + 2] = v.z; leaf.p[4 * q + 3] = v.w;
+        leaf.st[q] = sv[q];
+    }
+    if (TOP == 0) {  // the called node is itself the leaf: its rank is not a compile-time constant
+        if (site > (int)a.n_sites - 1) return;
+        explore_tail<0>(a, wc, e, site, rank, depth, node_base, branch, lane);
+    } else {
+        explore_tail20<TOP>(a, wc, e, leaf, site, rank, depth, node_base, branch, lane);
+    }
+}
+
 // INL = levels of the recursion below a node that explore_tail runs in registers (the node itself included: 1 + NS + ... +
 // NS^INL visits per transition).
-template <int INL, bool V4>
+template <int INL, int VEC>  // VEC: 4 / 20 = register-resident site rows for that many states, 0 = generic
 __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(BuildArgs a) {
     __shared__ Frames frames[BUILD_WAVES_PER_BLOCK];
     __shared__ WaveCursor cursors[BUILD_WAVES_PER_BLOCK];
@@ -204,6 +274,7 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
     if (lane == 0) { wc->base = 0; wc->used = TUPLE_CHUNK; }  // the first registration opens the first chunk
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    constexpr bool V4 = VEC == 4, V20 = VEC == 20;
     const int k = (int)a.k, S = (int)a.n_sites, NS = (int)a.n_states;
 
     // WordExplorer_v3 fields of the lane's current explorer
@@ -302,6 +373,14 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
                 case 1: run_tail4<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
                 case 2: if (INL >= 2) run_tail4<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
                 case 3: if (INL >= 3) run_tail4<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                default: break;
+                }
+            } else if (V20) {
+                switch (below) {
+                case 0: explore_tail<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 1: run_tail20<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 2: if (INL >= 2) run_tail20<(INL >= 2 ? 2 : 1)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 3: if (INL >= 3) run_tail20<(INL >= 3 ? 3 : 1)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
                 default: break;
                 }
             } else {
@@ -495,10 +574,18 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
             int inl = 3;
             if (const char *e = getenv("RK_BUILD_INLINE_LEVELS")) inl = atoi(e);  // developer knob
             const dim3 grid(blocks), block(64 * BUILD_WAVES_PER_BLOCK);
-            const bool v4 = d->n_states == 4 && !getenv("RK_BUILD_NO_V4");  // whole site rows in registers (DNA)
-            if (inl >= 3) { if (v4) hipLaunchKernelGGL((explore_kernel<3, true>), grid, block, 0, 0, a); else hipLaunchKernelGGL((explore_kernel<3, false>), grid, block, 0, 0, a); }
-            else if (inl == 2) { if (v4) hipLaunchKernelGGL((explore_kernel<2, true>), grid, block, 0, 0, a); else hipLaunchKernelGGL((explore_kernel<2, false>), grid, block, 0, 0, a); }
-            else { if (v4) hipLaunchKernelGGL((explore_kernel<1, true>), grid, block, 0, 0, a); else hipLaunchKernelGGL((explore_kernel<1, false>), grid, block, 0, 0, a); }
+            // whole site rows in registers for the two alphabets RAPPAS has (4 / 20 states); anything else: per-visit loads
+            const int vec = getenv("RK_BUILD_NO_VEC") ? 0 : (d->n_states == 4 ? 4 : (d->n_states == 20 ? 20 : 0));
+#define RK_LAUNCH_EXPLORE(I)                                                                                \
+    do {                                                                                                    \
+        if (vec == 4) hipLaunchKernelGGL((explore_kernel<I, 4>), grid, block, 0, 0, a);                     \
+        else if (vec == 20) hipLaunchKernelGGL((explore_kernel<I, 20>), grid, block, 0, 0, a);              \
+        else hipLaunchKernelGGL((explore_kernel<I, 0>), grid, block, 0, 0, a);                              \
+    } while (0)
+            if (inl >= 3) RK_LAUNCH_EXPLORE(3);
+            else if (inl == 2) RK_LAUNCH_EXPLORE(2);
+            else RK_LAUNCH_EXPLORE(1);
+#undef RK_LAUNCH_EXPLORE
             RK_HIP_TRY(hipGetLastError());
             RK_HIP_TRY(hipEventRecord(e1, 0));
             RK_HIP_TRY(hipEventSynchronize(e1));
