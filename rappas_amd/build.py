@@ -66,6 +66,26 @@ def build_engine(force=False, verbose=False):
     return ENGINE_SO
 
 
+HOST_BIN = os.path.join(ROOT, "rappas_amd", "bin", "rk_place")
+HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("rk_place_main.cpp", "rk_hostio.hpp")]
+
+
+def build_host_tools(force=False, verbose=False):
+    """rk_place: the native (C++17) FASTA + --jsondb -> .jplace driver over librappas_place.so."""
+    build_engine(force=False, verbose=verbose)
+    if not force and not _stale(HOST_BIN, HOST_SRC + [ENGINE_SO, os.path.join(ROOT, "include", "rappas_place.h")]):
+        return HOST_BIN
+    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", HOST_BIN, HOST_SRC[0], "-L" + os.path.dirname(ENGINE_SO),
+           "-lrappas_place", "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     build_engine(force="--force" in sys.argv, verbose=True)
     print("built:", ENGINE_SO)
+    print("built:", build_host_tools(force="--force" in sys.argv, verbose=True))

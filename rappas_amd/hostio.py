@@ -274,8 +274,22 @@ def jplace_placements(tree, names, n_rows, branch, score, lwr, guppy=False):
     return out
 
 
+_SHORT_ESC = {'"': '\\"', "\\": "\\\\", "\b": "\\b", "\f": "\\f", "\n": "\\n", "\r": "\\r", "\t": "\\t", "/": "\\/"}
+
+
 def _jstr(s):
-    return json.dumps(s, ensure_ascii=False).replace("/", "\\/")  # json-simple escapes '/'
+    """JSONValue.escape of json-simple 1.1 (the reference's lib/json_simple-1.1.jar): the short escapes incl. '\\/', and
+    \\uXXXX (upper-case hex) for U+0000-001F, U+007F-009F and U+2000-20FF; everything else verbatim."""
+    out = ['"']
+    for ch in s:
+        if ch in _SHORT_ESC:
+            out.append(_SHORT_ESC[ch])
+        elif ch <= "\u001f" or "\u007f" <= ch <= "\u009f" or "\u2000" <= ch <= "\u20ff":
+            out.append("\\u%04X" % ord(ch))
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
 
 
 def jplace_document(tree, placements, call_string="", guppy=False):

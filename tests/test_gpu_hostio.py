@@ -92,3 +92,24 @@ def test_build_tool_then_place_tool(tmp_path):
     by_name = {p["nm"][0][0]: p["p"][0][0] for p in js["placements"]}
     hits = sum(by_name.get(f"q{i}") == edge_of[truth[i]] for i in range(60))
     assert hits >= 57, hits
+
+
+@pytest.mark.parametrize("extra", [[], ["--amb", "max", "--keep-at-most", "5"], ["--guppy-compat", "--keep-factor", "0.2"]])
+def test_native_driver_writes_the_same_jplace(tmp_path, extra):
+    """rk_place (C++, rappas_amd/csrc/host) and `python -m rappas_amd.tools.place` over the same files: byte-identical .jplace."""
+    import subprocess
+    from rappas_amd import build
+    exe = build.build_host_tools()
+    db = synth.make_db(4, 6, 75, 3500, 30000, seed=13)
+    nwk = synth.make_newick(75, seed=6)
+    fasta, _ = _fasta(db, 300, 140, seed=10)
+    (tmp_path / "db.json").write_text(hostio.dump_jsondb(db, nwk))
+    (tmp_path / "q.fasta").write_text(fasta)
+    args = ["--jsondb", str(tmp_path / "db.json"), "--fasta", str(tmp_path / "q.fasta"), "--out", str(tmp_path / "out.jplace")] + extra
+    assert place_tool.main(args) == 0
+    py = (tmp_path / "out.jplace").read_bytes()
+    (tmp_path / "out.jplace").unlink()
+    r = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cpp = (tmp_path / "out.jplace").read_bytes()
+    assert cpp == py and len(py) > 10000

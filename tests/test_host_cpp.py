@@ -1,0 +1,91 @@
+"""The native host side (rappas_amd/csrc/host, `rk_place`) against its Python twin (rappas_amd/hostio.py): same trees,
+numbers, dedup and database parse, byte for byte.  The pieces exercised here need no GPU."""
+import hashlib
+import subprocess
+
+import numpy as np
+import pytest
+
+from rappas_amd import build, hostio, synth
+
+
+@pytest.fixture(scope="module")
+def rk_place():
+    return build.build_host_tools()
+
+
+def run(exe, *args):
+    return subprocess.run([exe, *args], check=True, capture_output=True, text=True).stdout
+
+
+@pytest.mark.parametrize("nwk", [
+    "((A:0.1,B:0.2)C:0.3,D:0.4)R;",
+    "(A:1,(B:2.5,C:1e-3):0.5,(D:1,E:1):1234.5);",
+    "((a:0.000001,b:12345678.9)x:0.5,(c:3,d:4)y:0.25,e:7)root:0.0;",
+    " ( ( t1:0.5 , t2:0.25 ) , t3 : 1 ) ; ",
+])
+def test_tree_numbering_and_jplace_string(rk_place, tmp_path, nwk):
+    f = tmp_path / "t.nwk"
+    f.write_text(nwk)
+    out = run(rk_place, "--emit-tree", str(f)).splitlines()
+    t = hostio.parse_newick(nwk)
+    assert out[0] == t.jplace_newick()
+    assert out[1] == hostio.write_newick(t, False, False, False)
+    assert out[2] == ("rooted" if t.rooted else "unrooted")
+    rows = [ln.split("\t") for ln in out[3:]]
+    assert [(int(r[0]), r[1], int(r[2]), int(r[3])) for r in rows] == \
+        [(n.id, n.label, n.jplace_edge, n.parent.id if n.parent is not None else -1) for n in t.nodes]
+
+
+def test_random_tree_matches(rk_place, tmp_path):
+    nwk = synth.make_newick(501, seed=4)
+    f = tmp_path / "t.nwk"
+    f.write_text(nwk)
+    assert run(rk_place, "--emit-tree", str(f)).splitlines()[0] == hostio.parse_newick(nwk).jplace_newick()
+
+
+def test_number_layouts(rk_place):
+    rng = np.random.default_rng(1)
+    floats = [0.0, -0.0, 1.0, 0.1, 1e-5, 3.4028235e38, 16777216.0, 0.05, -308.25, 0.33333334, 1e7, 9999999.0, 0.001, 9.999e-4]
+    floats += list((rng.standard_normal(40) * 10.0 ** rng.integers(-12, 12, 40)).astype(np.float32))
+    for x in floats:
+        x = np.float32(x)
+        assert run(rk_place, "--format-float", repr(float(x))).strip() == hostio.java_float_to_string(x), x
+    doubles = [0.0, 0.5, 1e-300, 0.1 + 0.2, 123.456, 1e7, 1.2345e10, 1e-3, 1e-4, float("nan"), float("inf")]
+    doubles += list(rng.standard_normal(40) * 10.0 ** rng.integers(-30, 30, 40))
+    for x in doubles:
+        assert run(rk_place, "--format-double", repr(float(x))).strip() == hostio.java_double_to_string(x), x
+
+
+def test_md5_and_dedup(rk_place, tmp_path):
+    for s in ["", "a", "ACGT" * 100, "x" * 55, "y" * 56, "z" * 64]:
+        assert run(rk_place, "--md5", s).strip() == hashlib.md5(s.encode()).hexdigest()
+    txt = "# c\n>r1 desc\nACGT\n\nAC-GT\n>r2\n  ACGTN  \n>r3 x y\nACGTACGT\n>empty\n>r4\nacgt\n>r5 dup of r1\nACGTACG-T\r\n"
+    f = tmp_path / "q.fa"
+    f.write_text(txt)
+    uniq, names = hostio.dedup_reads(hostio.read_fasta(txt))
+    got = [ln.split("\t") for ln in run(rk_place, "--dedup", str(f)).split("\n")[:-1]]
+    assert got == [[s] + n for (_, s), n in zip(uniq, names)]
+    assert names[0] == ["r1 desc", "r3", "r5"]
+
+
+def test_jsondb_parse(rk_place, tmp_path):
+    db = synth.make_db(4, 5, 9, 150, 700, seed=5)
+    nwk = synth.make_newick(9, seed=1)
+    f = tmp_path / "db.json"
+    f.write_text(hostio.dump_jsondb(db, nwk))
+    out = run(rk_place, "--load-jsondb", str(f)).splitlines()
+    d = hostio.load_jsondb(f.read_text())
+    head = out[0].split()
+    assert int(head[0]) == d["k"] and head[1] == hostio.java_float_to_string(d["thr"]) and head[2] == hostio.java_float_to_string(d["thr_log10"])
+    assert int(head[3]) == len(d["key_codes"]) and int(head[4]) == len(d["scores"])
+    assert out[1] == nwk
+    for r, line in enumerate(out[2:]):
+        parts = line.split()
+        a, b = int(d["row_offsets"][r]), int(d["row_offsets"][r + 1])
+        assert int(parts[0]) == int(d["key_codes"][r])
+        assert parts[1:] == [f"{int(d['branch_ids'][e])}:{hostio.java_float_to_string(d['scores'][e])}" for e in range(a, b)]
+
+
+def test_string_escaping_follows_json_simple():
+    assert hostio._jstr('a/b"c\\d\n\x01\x7f é') == '"a\\/b\\"c\\\\d\\n\\u0001\\u007F\\u2028é"'
