@@ -13,4 +13,20 @@ LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 RK_LIB=
 gcc -O1 -g -std=c99 -fPIC -ffp-contract=off -fsanitize=address,undefined -shared -o /tmp/liboracle_asan.so oracle/rappas_oracle.c oracle/rappas_build_oracle.c -lm
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 RO_LIB=/tmp/liboracle_asan.so \
       python -m pytest tests/test_oracle_golden.py tests/test_oracle_build.py -q -x -p no:cacheprovider
-echo "asan/ubsan host pass: OK"
+echo "asan/ubsan engine host code + oracles: OK"
+# the native host side (rk_hostio.hpp through rk_place's device-free modes) under the same sanitizers
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -o /tmp/rk_place_asan rappas_amd/csrc/host/rk_place_main.cpp \
+    -Lrappas_amd -lrappas_place -Wl,-rpath,$PWD/rappas_amd
+T=$(mktemp -d)
+printf '((A:0.1,B:0.2)C:0.3,(D:0.4,E:1e-3)F:1234.5)R;' > $T/t.nwk
+printf '>r1 d\nACGT\nAC-GT\n>r2\nACGTACGT\n>r3 x\nACGTACG-T\n' > $T/q.fa
+python - "$T" <<'PY'
+import sys
+from rappas_amd import hostio, synth
+open(sys.argv[1] + "/db.json", "w").write(hostio.dump_jsondb(synth.make_db(4, 5, 9, 150, 700, seed=5), synth.make_newick(9, seed=1)))
+PY
+for args in "--emit-tree $T/t.nwk" "--dedup $T/q.fa" "--load-jsondb $T/db.json" "--format-float 0.1" "--format-double 1e-300" "--md5 abc"; do
+  ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 /tmp/rk_place_asan $args > /dev/null
+done
+rm -rf $T
+echo "asan/ubsan native host side: OK"
