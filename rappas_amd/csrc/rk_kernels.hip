@@ -22,7 +22,7 @@
 #define RK_ROW_NT 0
 #endif
 #ifndef RK_ABLATE
-#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR (outputs are then wrong)
+#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row (outputs are then wrong)
 #endif
 #include "../../include/rappas_place.h"
 
@@ -930,9 +930,10 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                         const u32 rb = (u32)off8 * 8u;  // byte offset of the row (128-byte aligned units)
                         u32 *it32 = (u32 *)items;
                         if (nch[u] > 0) it32[base] = rb;
-                        if (nch[u] > 1) it32[base + 1] = rb + 128u;
+                        // (RK_ABLATE & 32, timing only: later chunks re-read the row's first unit -- same steps, fewer requests)
+                        if (nch[u] > 1) it32[base + 1] = (RK_ABLATE & 32) ? rb : rb + 128u;
                         for (u32 c = 2; __any(c < nch[u]); c++)
-                            if (c < nch[u]) it32[base + (int)c] = rb + c * 128u;
+                            if (c < nch[u]) it32[base + (int)c] = (RK_ABLATE & 32) ? rb : rb + c * 128u;
                         continue;
                     }
                     // most rows are 1-2 chunks: those are written without a wave vote, the rest in a voted loop
