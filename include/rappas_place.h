@@ -134,6 +134,14 @@ int rk_db_get_info(const rk_db *db, rk_db_info *info);
 int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                    const uint64_t *seq_off, rk_result *out, rk_counters *counters);
 
+/* The same over several GPUs from ONE host process (RAPPAS is a single JVM): dbs[g] are handles of the same database created
+ * on different devices (rk_db_create with desc.device = g); the batch is cut into n_dbs contiguous shards, shard g goes to
+ * dbs[g] on its own host thread, and every shard writes its slice of the caller's result arrays -- reads are independent
+ * (PlacementProcess.java:1067-1075 resets all per-read state), so there is no exchange step and no collective.  Results are
+ * identical to one rk_place_batch call over the whole batch. */
+int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
+                         const uint64_t *seq_off, rk_result *out, rk_counters *counters);
+
 /* Page-locked host memory for the buffers handed to rk_place_batch: with pinned input/output the host path runs at
  * ~1.3e8 reads/s (C2, 150 bp) instead of ~6e7 with pageable memory.  A JVM can wrap it with NewDirectByteBuffer. */
 void *rk_host_alloc(uint64_t bytes);

@@ -71,6 +71,8 @@ EXPORTS = {
     "rk_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(rk_db_info)]),
     "rk_place_batch": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.POINTER(rk_result), C.POINTER(rk_counters)]),
+    "rk_place_batch_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rk_params), C.c_uint64, C.c_void_p,
+                                       C.c_void_p, C.POINTER(rk_result), C.POINTER(rk_counters)]),
     "rk_host_alloc": (C.c_void_p, [C.c_uint64]),
     "rk_host_free": (None, [C.c_void_p]),
     "rk_packed_words": (C.c_uint32, [C.c_void_p, C.c_uint32]),

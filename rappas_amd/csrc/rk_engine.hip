@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace rk;
@@ -499,6 +500,45 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
 extern "C" int rk_db_get_info(const rk_db *db, rk_db_info *info) {
     if (!db || !info) return fail(RK_ERR_INVALID, "rk_db_get_info: null argument");
     *info = db->info;
+    return RK_OK;
+}
+
+static int check_params(const rk_params *p);
+
+// one host thread per device handle; contiguous shards; see include/rappas_place.h
+extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_params *p, uint64_t n_reads,
+                                    const uint8_t *seq_ascii, const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
+    if (!dbs || n_dbs == 0 || !out) return fail(RK_ERR_INVALID, "rk_place_batch_multi: null argument");
+    for (uint32_t g = 0; g < n_dbs; g++)
+        if (!dbs[g]) return fail(RK_ERR_INVALID, "rk_place_batch_multi: dbs[%u] is null", g);
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_dbs == 1 || n_reads == 0) return rk_place_batch(dbs[0], p, n_reads, seq_ascii, seq_off, out, counters);
+    if (!seq_ascii || !seq_off) return fail(RK_ERR_INVALID, "rk_place_batch_multi: null reads");
+    if (!out->n_rows || !out->branch || !out->score || !out->lwr || !out->flags) return fail(RK_ERR_INVALID, "rk_place_batch_multi: null result array");
+    const uint32_t K = p->keep_at_most;
+    std::vector<int> codes(n_dbs, RK_OK);
+    std::vector<std::string> msgs(n_dbs);
+    std::vector<rk_counters> cts(n_dbs);
+    std::vector<std::thread> workers;
+    for (uint32_t g = 0; g < n_dbs; g++) {
+        const uint64_t lo = n_reads * g / n_dbs, hi = n_reads * (g + 1) / n_dbs;
+        workers.emplace_back([&, g, lo, hi]() {
+            cts[g] = rk_counters{};
+            if (hi == lo) return;
+            rk_result r{out->n_rows + lo, out->branch + lo * K, out->score + lo * K, out->lwr + lo * K, out->flags + lo};
+            codes[g] = rk_place_batch(dbs[g], p, hi - lo, seq_ascii, seq_off + lo, &r, &cts[g]);
+            if (codes[g] != RK_OK) msgs[g] = rk_last_error();  // the message lives in this thread: hand it over
+        });
+    }
+    for (std::thread &t : workers) t.join();
+    rk_counters total{};
+    for (uint32_t g = 0; g < n_dbs; g++) {
+        if (codes[g] != RK_OK) return fail(codes[g], "rk_place_batch_multi: shard %u: %s", g, msgs[g].c_str());
+        total.reads += cts[g].reads; total.placed += cts[g].placed; total.unplaced += cts[g].unplaced;
+        total.bad_char += cts[g].bad_char; total.too_short += cts[g].too_short; total.ambiguous += cts[g].ambiguous;
+    }
+    if (counters) *counters = total;
     return RK_OK;
 }
 

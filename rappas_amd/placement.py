@@ -133,6 +133,25 @@ class PlacementProcess:
         out.counters = {f: getattr(ct, f) for f, _ in rk_counters._fields_}
         return out
 
+    def processQueriesMulti(self, dbs, seq, seq_off, keepAtMost=7, keepFactor=0.01, treatAmbiguities=True,
+                            treatAmbiguitiesWithMax=False):
+        """processQueries over several device handles of the same database from this one process
+        (rk_place_batch_multi: contiguous shards, one host thread per handle, no collective)."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        n = seq_off.shape[0] - 1
+        K = keepAtMost
+        out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
+                         np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
+        res = rk_result(_ptr(out.n_rows), _ptr(out.branch), _ptr(out.score), _ptr(out.lwr), _ptr(out.flags))
+        p = self._params(keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax)
+        ct = rk_counters()
+        handles = (C.c_void_p * len(dbs))(*[d.handle for d in dbs])
+        _lib.check(self._lib.rk_place_batch_multi(handles, len(dbs), C.byref(p), n, _ptr(seq), _ptr(seq_off), C.byref(res),
+                                                  C.byref(ct)))
+        out.counters = {f: getattr(ct, f) for f, _ in rk_counters._fields_}
+        return out
+
     # ---- device-resident variant (torch tensors only carry the memory and the stream) ----
     def place_packed(self, packed, fixed_len=0, lens=None, flags_in=None, seq_ascii=None, seq_off=None, out=None,
                      keepAtMost=7, keepFactor=0.01, treatAmbiguities=True, treatAmbiguitiesWithMax=False,

@@ -312,3 +312,25 @@ def test_scores_below_threshold_take_the_general_first_touch(lanes, amb):
     sdb = dataclasses.replace(sdb, scores=sc)
     seq, off = synth.make_reads(4, 3000, 150, seed=4, amb_rate=0.001)
     run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", lanes, amb)
+
+
+def test_place_batch_multi_equals_single_call(c2_small):
+    """rk_place_batch_multi: several device handles of one database driven from one process, contiguous shards on host
+    threads.  (A one-GPU box: the handles share device 0 -- the sharding, threading and result placement are what is tested.)"""
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 3001, 150, seed=12, amb_rate=0.001, var_len=100)
+    dbs = [ra.PhyloKmerDB.from_synth(sdb) for _ in range(3)]
+    try:
+        pp = ra.PlacementProcess(dbs[0])
+        one = pp.processQueries(seq, off)
+        many = pp.processQueriesMulti(dbs, seq, off)
+        for f in ("n_rows", "branch", "flags"):
+            assert np.array_equal(getattr(one, f), getattr(many, f)), f
+        assert np.array_equal(one.score.view(np.uint32), many.score.view(np.uint32)) and np.array_equal(one.lwr, many.lwr)
+        assert one.counters == many.counters
+        compare_with_oracle(many, odb.place(seq, off), odb, seq, off)
+        few = pp.processQueriesMulti(dbs, seq[:int(off[2])], off[:3])  # fewer reads than handles: empty shards
+        assert np.array_equal(few.branch, one.branch[:2])
+    finally:
+        for d in dbs:
+            d.close()
