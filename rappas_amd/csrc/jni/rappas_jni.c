@@ -10,6 +10,8 @@
 #include <jni.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 #include "rappas_place.h"
 
 static void throw_rk(JNIEnv *env, const char *where) {
@@ -78,4 +80,58 @@ JNIEXPORT void JNICALL Java_core_algos_NativePlacement_placeBatch(JNIEnv *env, j
 JNIEXPORT void JNICALL Java_core_algos_NativePlacement_dbDestroy(JNIEnv *env, jclass cls, jlong db) {
     (void)env; (void)cls;
     rk_db_destroy((rk_db *)(intptr_t)db);
+}
+
+/* Object[] buildDb(int alphabet, int k, int nNodes, int nSites, int nStates, byte[] states, float[] ppLog10, char[] nodeBranch,
+ *                  float thrLog10, boolean gapJumps, boolean limitTo1Jump, int[] gapOff, int[] gapLen, int device)
+ * -> {long[] keyCodes, long[] rowOffsets, char[] branchIds, float[] scores}
+ * The Java caller flattens arpr.getPProbas() for nodesTested ([node][site][rank]) and align.getGapIntervals() (CSR);
+ * replaces the loops of src/main_v2/Main_DBBUILD_3.java:648-750. */
+JNIEXPORT jobjectArray JNICALL Java_core_algos_NativePlacement_buildDb(JNIEnv *env, jclass cls, jint alphabet, jint k, jint nNodes,
+        jint nSites, jint nStates, jbyteArray states, jfloatArray ppLog10, jcharArray nodeBranch, jfloat thrLog10,
+        jboolean gapJumps, jboolean limitTo1Jump, jintArray gapOff, jintArray gapLen, jint device) {
+    (void)cls;
+    rk_build_desc d;
+    rk_built_db b;
+    memset(&d, 0, sizeof d);
+    d.alphabet = (uint32_t)alphabet; d.k = (uint32_t)k; d.n_nodes = (uint32_t)nNodes; d.n_sites = (uint32_t)nSites;
+    d.n_states = (uint32_t)nStates; d.do_gap_jumps = gapJumps ? 1u : 0u; d.limit_to_1_jump = limitTo1Jump ? 1u : 0u;
+    d.thr_log10 = thrLog10; d.device = device;
+    jbyte *st = (*env)->GetByteArrayElements(env, states, NULL);
+    jfloat *pp = (*env)->GetFloatArrayElements(env, ppLog10, NULL);
+    jchar *nb = (*env)->GetCharArrayElements(env, nodeBranch, NULL);
+    jint *go = gapJumps ? (*env)->GetIntArrayElements(env, gapOff, NULL) : NULL;
+    jint *gl = gapJumps ? (*env)->GetIntArrayElements(env, gapLen, NULL) : NULL;
+    d.states = (const uint8_t *)st; d.pp_log10 = pp; d.node_branch = (const uint16_t *)nb;
+    d.gap_off = (const uint32_t *)go; d.gap_len = (const int32_t *)gl;
+    int rc = rk_build_db(&d, &b);
+    (*env)->ReleaseByteArrayElements(env, states, st, JNI_ABORT);
+    (*env)->ReleaseFloatArrayElements(env, ppLog10, pp, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, nodeBranch, nb, JNI_ABORT);
+    if (go) (*env)->ReleaseIntArrayElements(env, gapOff, go, JNI_ABORT);
+    if (gl) (*env)->ReleaseIntArrayElements(env, gapLen, gl, JNI_ABORT);
+    if (rc != RK_OK) { throw_rk(env, "rk_build_db"); return NULL; }
+    jobjectArray res = NULL;
+    if (b.n_entries > 0x7FFFFFF0ull || b.n_keys > 0x7FFFFFF0ull) {
+        jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
+        if (ex) (*env)->ThrowNew(env, ex, "rk_build_db: result does not fit Java arrays; build per node batch");
+    } else {
+        jlongArray kc = (*env)->NewLongArray(env, (jsize)b.n_keys);
+        jlongArray ro = (*env)->NewLongArray(env, (jsize)b.n_keys + 1);
+        jcharArray br = (*env)->NewCharArray(env, (jsize)b.n_entries);
+        jfloatArray sc = (*env)->NewFloatArray(env, (jsize)b.n_entries);
+        jclass obj = (*env)->FindClass(env, "java/lang/Object");
+        if (kc && ro && br && sc && obj && (res = (*env)->NewObjectArray(env, 4, obj, NULL))) {
+            (*env)->SetLongArrayRegion(env, kc, 0, (jsize)b.n_keys, (const jlong *)b.key_codes);
+            (*env)->SetLongArrayRegion(env, ro, 0, (jsize)b.n_keys + 1, (const jlong *)b.row_offsets);
+            (*env)->SetCharArrayRegion(env, br, 0, (jsize)b.n_entries, (const jchar *)b.branch_ids);
+            (*env)->SetFloatArrayRegion(env, sc, 0, (jsize)b.n_entries, b.scores);
+            (*env)->SetObjectArrayElement(env, res, 0, kc);
+            (*env)->SetObjectArrayElement(env, res, 1, ro);
+            (*env)->SetObjectArrayElement(env, res, 2, br);
+            (*env)->SetObjectArrayElement(env, res, 3, sc);
+        }
+    }
+    rk_built_free(&b);
+    return res;
 }
