@@ -21,6 +21,10 @@ using namespace rk;
 #ifndef RK_WG_MIN_BRANCHES
 #define RK_WG_MIN_BRANCHES 8192u  // above this a single-wave score vector leaves <= 4 waves per CU: use place_wg_kernel
 #endif
+#ifndef RK_WG_MIN_MEAN_ROW
+#define RK_WG_MIN_MEAN_ROW 64.0     // ... for rows at least this long on average ...
+#define RK_WG_ALWAYS_BRANCHES 16000u  // ... or, whatever the rows, above this many branches
+#endif
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
 #endif
@@ -280,7 +284,11 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     // and preceded by one 64-byte INDEX line: u16 split[i-1] = number of entries with branch < floor(i * n_branches / 32),
     // i = 1..32, so a wave finds its slice of a row with two 2-byte loads.  Descriptors still point at the first
     // entry line; the other kernels never look at the index line.
-    const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES;
+    // ... unless the rows are short: a workgroup's eight waves then each scan a sliver of every row, and one wave per read on
+    // a few resident score vectors does better (measured, rows of ~13 entries: 12 001 branches 29 vs 20 Mreads/s; the
+    // workgroup kernel is ahead again from ~16 000 branches on, where two score vectors fill a CU, and always for long rows).
+    const double mean_len = n_keys ? (double)n_entries / (double)n_keys : 0.0;
+    const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES && (mean_len >= RK_WG_MIN_MEAN_ROW || d->n_branches > RK_WG_ALWAYS_BRANCHES);
     img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
     // slot-offset images: 128-byte units (ROW_UNIT = 16 entries), so a chunk of 16 entries is ONE aligned 128-byte request;
@@ -568,7 +576,7 @@ extern "C" int rk_set_lanes_per_read(rk_db *db, uint32_t lanes) {
     if (lanes != 0 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64)
         return fail(RK_ERR_INVALID, "rk_set_lanes_per_read: lanes must be 0 (auto), 8, 16, 32 or 64");
     if (lanes != 0 && db->indexed)
-        return fail(RK_ERR_UNSUPPORTED, "rk_set_lanes_per_read: large-tree images (n_branches > %u) always use the workgroup-per-read kernel", RK_WG_MIN_BRANCHES);
+        return fail(RK_ERR_UNSUPPORTED, "rk_set_lanes_per_read: this database uses the large-tree image (n_branches > %u, long rows): always the workgroup-per-read kernel", RK_WG_MIN_BRANCHES);
     db->lanes_per_read = lanes;
     return RK_OK;
 }
@@ -592,11 +600,13 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
     auto bytes_for = [&](uint32_t G, uint32_t cap) { return (size_t)(64 / G) * (fixed + (size_t)cap * 8); };
     uint32_t G = db->lanes_per_read;
     if (G == 0) {
+        // Throughput follows the reads in flight per CU (LDS capacity / score-vector size) and, at equal reads in flight, prefers
+        // narrower groups as long as enough waves remain to hide latency.  Measured on C2-like DBs (scripts/tree_size_sweep.py):
+        // 999 branches: 16 lanes (8 waves) 323 Mreads/s; 1999: 32 lanes (8 waves) 185 vs 16 lanes (4 waves) 132 vs 64 lanes 112;
+        // 3999: 32 lanes (4 waves) 88 vs 64 lanes (9 waves) 62; 7999: 64 lanes (4 waves) 46 vs 32 lanes (2 waves) 35.
         G = 64;
-        for (uint32_t cand : {16u, 32u, 64u}) {
-            if (cand < keep_at_most) continue;
-            if (bytes_for(cand, cand + 3 * RK_RING + 40) <= target) { G = cand; break; }
-        }
+        if (keep_at_most <= 16 && bytes_for(16, 16 + 3 * RK_RING + 40) <= db->lds_per_cu / 8) G = 16;
+        else if (keep_at_most <= 32 && bytes_for(32, 32 + 3 * RK_RING + 40) <= db->lds_per_cu / 4) G = 32;
     }
     if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
     const uint32_t NG = 64 / G, pu = probe_unroll(G);
