@@ -312,7 +312,7 @@ __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list,
 
 // ------------------------------------------------------------------------------------------------
 // accumulate by chunks, general form (any group width, any blob size; G == 16 with 32-bit offsets takes
-// accumulate_chunks16 below instead): the hit list holds one item per CHUNK (<= G entries of one row, whole 64-byte
+// accumulate_units below instead): the hit list holds one item per CHUNK (<= G entries of one row, whole 64-byte
 // lines), written in k-mer order by the probe phase.  A step is then: decode one item, one entry load per lane, one
 // LDS read-modify-write -- no row cursor.  Items are 32-bit when the row blob is < 4 GiB:
 //   (64-byte line index of the chunk) << 4 | (lines in the chunk),   else the 64-bit descriptor format.
@@ -374,12 +374,14 @@ __device__ __forceinline__ void accumulate_chunks(u32 *S, u32 nb, const typename
 }
 
 // ------------------------------------------------------------------------------------------------
-// accumulate, G == 16 with 32-bit offsets (the usual geometry): rows are stored in aligned 128-byte units of 16
-// entries, so a chunk is exactly one unit -- one 128-byte request for the group -- and its item is just the unit's
-// byte offset.  Rows are read through a raw buffer descriptor over the blob; list slots past a group's own count
-// hold ITEM_FILLER, an offset outside the buffer: the load returns zeros without touching memory and the update
-// goes to the scratch slot.  A step is then: item + lane offset, one buffer load, one LDS read-modify-write -- no
-// bounds test, no count test, no 64-bit address arithmetic.  `wcnt` = the largest count among the wave's groups.
+// accumulate, groups of 16 / 32 / 64 lanes with 32-bit offsets (every geometry the engine picks by itself): rows are
+// stored in aligned 128-byte units of 16 entries, a chunk is G/16 units -- one 128-byte request per 16 lanes -- and its
+// item is the first unit's byte offset | (units of the chunk that belong to the row - 1) in the low bits.  Rows are read
+// through a raw buffer descriptor over the blob; lanes whose unit lies beyond the row, and list slots past a group's own
+// count (ITEM_FILLER), get an offset outside the buffer: the load returns zeros without touching memory and the update
+// goes to the scratch slot.  A step is then: item (+ unit test for G > 16) + lane offset, one buffer load, one LDS
+// read-modify-write -- no bounds test, no count test, no 64-bit address arithmetic.  `wcnt` = the largest count among the
+// wave's groups.
 // ------------------------------------------------------------------------------------------------
 constexpr u32 ITEM_FILLER = 0xFFFFFF00u;
 typedef u32 v2u32 __attribute__((ext_vector_type(2)));
@@ -388,14 +390,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_resource(const DbView &db
     return __builtin_amdgcn_make_buffer_rsrc((void *)db.rows, (short)0, (int)(u32)db.rows_bytes, 0x00020000);
 }
 
-template <int U, bool MONO>
-__device__ __forceinline__ void accumulate_chunks16(u32 *S, const u32 *items, int wcnt, u32 li,
-                                                    __amdgpu_buffer_rsrc_t rs, float QT, float T) {
+template <int G, int U, bool MONO>
+__device__ __forceinline__ void accumulate_units(u32 *S, const u32 *items, int wcnt, u32 li,
+                                                 __amdgpu_buffer_rsrc_t rs, float QT, float T) {
     const u32 li8 = li * 8;
+    const u32 my_unit = li >> 4;  // which 128-byte unit of the chunk this lane reads
     u32 sb[U], it[U];
     float sc[U];
     auto issue = [&](u32 item, u32 &b, float &v) {
-        u32 off = item + li8;
+        u32 off = item + li8;  // G == 16: the low bits of an item are zero
+        if (G > 16) off = (my_unit <= (item & 7u)) ? (item & ~127u) + li8 : ITEM_FILLER;
         if (RK_ABLATE & 16) off = li8;
         const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
         b = e.x;
@@ -752,7 +756,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     const u32 k = a.db.k;
     const float T = a.db.T;
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
-    constexpr bool FAST16 = (G == 16 && !WIDE);  // buffer-addressed one/two-line chunks (accumulate_chunks16)
+    constexpr bool FAST16 = (G >= 16 && !WIDE);  // buffer-addressed unit chunks (accumulate_units)
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     // chunk items the list can take (3U slots of slack for the read-ahead of accumulate_chunks)
     const int cap_items = (int)(a.list_cap * (sizeof(u64) / sizeof(item_t))) - 3 * U - 2;
@@ -799,15 +803,17 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
             if (FAST16) {
                 // the longest list of the wave's four groups sets the step count; shorter lists are padded with fillers
                 int wcnt = __builtin_amdgcn_readlane(cnt, 0);
-                wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 16));
-                wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 32));
-                wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 48));
+                if (G <= 32) wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 32));
+                if (G == 16) {
+                    wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 16));
+                    wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 48));
+                }
                 for (int i = cnt + (int)li; i < wcnt + 2 * U; i += G) ((u32 *)items)[i] = ITEM_FILLER;
                 wave_lds_fence();
                 RK_STAMP(3);
                 if (!(RK_ABLATE & 1)) {
-                    if (a.db.mono) accumulate_chunks16<U, true>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
-                    else accumulate_chunks16<U, false>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
+                    if (a.db.mono) accumulate_units<G, U, true>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
+                    else accumulate_units<G, U, false>(S, (const u32 *)items, wcnt, li, rows_rs, QT, T);
                 }
                 wave_lds_fence();
                 RK_STAMP(4);
@@ -928,12 +934,21 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                     const int base = cnt + (int)excl[u];
                     if (FAST16) {
                         const u32 rb = (u32)off8 * 8u;  // byte offset of the row (128-byte aligned units)
+                        constexpr u32 UPC = G / 16;     // units per chunk
+                        const u32 units = lenp >> 4;    // units of the row
                         u32 *it32 = (u32 *)items;
-                        if (nch[u] > 0) it32[base] = rb;
                         // (RK_ABLATE & 32, timing only: later chunks re-read the row's first unit -- same steps, fewer requests)
-                        if (nch[u] > 1) it32[base + 1] = (RK_ABLATE & 32) ? rb : rb + 128u;
+                        auto item_of = [&](u32 c) {
+                            const u32 left = units - c * UPC;
+                            const u32 first = ((RK_ABLATE & 32) && c) ? rb : rb + c * (UPC * 128u);
+                            if (UPC == 1) return first;  // one unit per chunk: nothing to encode
+                            return first | ((left < UPC ? left : UPC) - 1u);
+                        };
+                        // most rows are 1-2 chunks: those are written without a wave vote, the rest in a voted loop
+                        if (nch[u] > 0) it32[base] = item_of(0);
+                        if (nch[u] > 1) it32[base + 1] = item_of(1);
                         for (u32 c = 2; __any(c < nch[u]); c++)
-                            if (c < nch[u]) it32[base + (int)c] = (RK_ABLATE & 32) ? rb : rb + c * 128u;
+                            if (c < nch[u]) it32[base + (int)c] = item_of(c);
                         continue;
                     }
                     // most rows are 1-2 chunks: those are written without a wave vote, the rest in a voted loop
