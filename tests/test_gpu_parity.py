@@ -334,3 +334,39 @@ def test_place_batch_multi_equals_single_call(c2_small):
     finally:
         for d in dbs:
             d.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomised_configurations(seed):
+    """Differential sweep: random alphabet / k / tree size / row lengths / read lengths / parameters / table flavour / lane-group
+    width, engine against oracle (small sizes, seeded)."""
+    rng = np.random.default_rng(1000 + seed)
+    alphabet = 4 if rng.random() < 0.7 else 20
+    k = int(rng.integers(3, 9)) if alphabet == 4 else int(rng.integers(2, 5))
+    nb = int(rng.choice([1, 2, 7, 40, 200, 999, 2500, 5000, 9000]))
+    space = alphabet ** k
+    n_keys = int(min(space, rng.integers(1, 4000)))
+    mean_len = float(rng.choice([1.0, 3.0, 12.0, 40.0, 150.0]))
+    sdb = synth.make_db(alphabet, k, nb, n_keys, max(n_keys, int(n_keys * mean_len)), seed=seed)
+    if rng.random() < 0.3:  # scores below the threshold: the general first-touch path
+        sc = sdb.scores.copy()
+        sc[::3] = sc[::3] + np.float32(sdb.thr_log10)
+        import dataclasses
+        sdb = dataclasses.replace(sdb, scores=sc)
+    rl = int(rng.choice([k - 1, k, k + 1, 30, 150, 400]))
+    seq, off = synth.make_reads(alphabet, int(rng.integers(1, 600)), max(1, rl), seed=seed + 7,
+                                amb_rate=float(rng.choice([0.0, 0.003, 0.03])), bad_rate=float(rng.choice([0.0, 0.0, 0.002])),
+                                var_len=int(rng.choice([0, 0, max(1, rl // 2)])))
+    K = int(rng.choice([1, 3, 7, 7, 12, 16]))
+    lanes = int(rng.choice([0, 0, 16, 32, 64])) if K <= 16 else 0
+    odb = O.OracleDB.from_synth(sdb)
+    med = float(np.median(odb.place(seq, off, keep_at_most=K)["score"][:, 0])) if len(off) > 1 else 0.0
+    kw = dict(keepAtMost=K, keepFactor=float(rng.choice([0.0, 0.01, 0.5, 1.0])))
+    if rng.random() < 0.25 and np.isfinite(med):
+        kw["ns_bound"] = med
+    try:
+        run_case(sdb, odb, seq, off, str(rng.choice(["direct", "direct8", "hash"])), lanes, str(rng.choice(["mean", "max", "skip"])), **kw)
+    except ra.RkError as e:
+        # the only configurations the engine may refuse: lane groups narrower than keep_at_most, or a fixed width on a large-tree image
+        assert ("lanes_per_read" in str(e) or "keep_at_most" in str(e)), e
+        pytest.skip(f"configuration refused as documented: {e}")
