@@ -125,3 +125,33 @@ def test_build_matches_committed_vectors(path):
     assert np.array_equal(got.branch_ids, exp["branch_ids"])
     assert np.array_equal(got.scores.view(np.uint32), exp["score_bits"])
     assert got.tuples == exp["tuples"] and got.visits == exp["visits"]
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_randomised_tables(seed):
+    """Differential sweep of rk_build_db against its oracle: random alphabet / k / table shape / state counts / thresholds /
+    gap intervals / jump mode (small sizes, seeded)."""
+    rng = np.random.default_rng(500 + seed)
+    alphabet = 4 if rng.random() < 0.65 else 20
+    k = int(rng.integers(2, 9)) if alphabet == 4 else int(rng.integers(2, 4))
+    n_nodes, n_sites = int(rng.integers(1, 12)), int(rng.integers(1, 40))
+    states, pp, nb = synth.make_pp_tables(alphabet, n_nodes, n_sites, seed=seed, peaked=float(rng.choice([0.3, 0.8, 0.99])),
+                                          n_branches=int(rng.integers(1, 9)))
+    if rng.random() < 0.3:  # fewer ranked states than the alphabet has (the generic, non-vector tails)
+        ns = int(rng.integers(1, alphabet))
+        states, pp = np.ascontiguousarray(states[:, :, :ns]), np.ascontiguousarray(pp[:, :, :ns])
+    omega = float(rng.choice([0.8, 1.0, 1.5, 2.5]))
+    _, T = synth.thresholds(omega, alphabet, k)
+    kw = {}
+    if rng.random() < 0.4:
+        rows = []
+        for _ in range(4):
+            r = ["A"] * n_sites
+            for _ in range(3):
+                s = int(rng.integers(0, n_sites))
+                for t in range(s, min(n_sites, s + int(rng.integers(1, 5)))):
+                    r[t] = "-"
+            rows.append("".join(r))
+        off, lens = synth.gap_intervals(rows)
+        kw = dict(gap_off=off, gap_len=lens, limit_to_1_jump=bool(rng.random() < 0.5))
+    _check(alphabet, k, states, pp, nb, T, **kw)
