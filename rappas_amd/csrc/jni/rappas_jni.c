@@ -135,3 +135,41 @@ JNIEXPORT jobjectArray JNICALL Java_core_algos_NativePlacement_buildDb(JNIEnv *e
     rk_built_free(&b);
     return res;
 }
+
+/* void placeBatchMulti(long[] dbs, byte[] seqs, long[] offs, int keepAtMost, float keepFactor, int ambMode, float nsBound,
+ *                      byte[] nRows, char[] branch, float[] score, double[] lwr, int[] flags)
+ * dbs[g] = dbCreate(..., device = g): one handle per GPU, contiguous shards on host threads inside the library. */
+JNIEXPORT void JNICALL Java_core_algos_NativePlacement_placeBatchMulti(JNIEnv *env, jclass cls, jlongArray dbs, jbyteArray seqs,
+        jlongArray offs, jint keepAtMost, jfloat keepFactor, jint ambMode, jfloat nsBound, jbyteArray nRows,
+        jcharArray branch, jfloatArray score, jdoubleArray lwr, jintArray flags) {
+    (void)cls;
+    rk_params p = {(uint32_t)keepAtMost, keepFactor, (uint32_t)ambMode, nsBound};
+    const uint64_t n = (uint64_t)(*env)->GetArrayLength(env, offs) - 1;
+    const jsize nd = (*env)->GetArrayLength(env, dbs);
+    rk_db *handles[64];
+    if (nd < 1 || nd > 64) {
+        jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+        if (ex) (*env)->ThrowNew(env, ex, "placeBatchMulti: 1..64 database handles");
+        return;
+    }
+    jlong *h = (*env)->GetLongArrayElements(env, dbs, NULL);
+    for (jsize g = 0; g < nd; g++) handles[g] = (rk_db *)(intptr_t)h[g];
+    (*env)->ReleaseLongArrayElements(env, dbs, h, JNI_ABORT);
+    jbyte *s = (*env)->GetByteArrayElements(env, seqs, NULL);
+    jlong *o = (*env)->GetLongArrayElements(env, offs, NULL);
+    jbyte *nr = (*env)->GetByteArrayElements(env, nRows, NULL);
+    jchar *b = (*env)->GetCharArrayElements(env, branch, NULL);
+    jfloat *sc = (*env)->GetFloatArrayElements(env, score, NULL);
+    jdouble *w = (*env)->GetDoubleArrayElements(env, lwr, NULL);
+    jint *f = (*env)->GetIntArrayElements(env, flags, NULL);
+    rk_result out = {(uint8_t *)nr, (uint16_t *)b, sc, w, (uint32_t *)f};
+    int rc = rk_place_batch_multi(handles, (uint32_t)nd, &p, n, (const uint8_t *)s, (const uint64_t *)o, &out, NULL);
+    (*env)->ReleaseByteArrayElements(env, seqs, s, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, offs, o, JNI_ABORT);
+    (*env)->ReleaseByteArrayElements(env, nRows, nr, 0);
+    (*env)->ReleaseCharArrayElements(env, branch, b, 0);
+    (*env)->ReleaseFloatArrayElements(env, score, sc, 0);
+    (*env)->ReleaseDoubleArrayElements(env, lwr, w, 0);
+    (*env)->ReleaseIntArrayElements(env, flags, f, 0);
+    if (rc != RK_OK) throw_rk(env, "rk_place_batch_multi");
+}
