@@ -1270,6 +1270,67 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
             d[w] = ((u32)w < W) ? lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p))) : 0ull;
         const u32 maxlen = max(max((u32)d[0] & DESC_LEN_MASK, (u32)d[1] & DESC_LEN_MASK),
                                max((u32)d[2] & DESC_LEN_MASK, (u32)d[3] & DESC_LEN_MASK));
+        if (maxlen <= 16) {
+            // every alternative's row fits 16 lanes: lane = (alternative, entry), so the pow() of pass 1 and the log10() of
+            // pass 2 are each evaluated ONCE for all alternatives together; only the cheap LDS updates run alternative by
+            // alternative, in the reference's order (the float += double of :1155 rounds per alternative)
+            const u32 w = lane >> 4, e = lane & 15u;
+            const u64 dw = w == 0 ? d[0] : (w == 1 ? d[1] : (w == 2 ? d[2] : d[3]));
+            u32 x = 0xFFFFu;
+            float v = 0.0f;
+            if (w < W && e < ((u32)dw & DESC_LEN_MASK)) load_entry(a.db, dw, e, x, v);
+            const bool have = x != 0xFFFFu;
+            const double pw = (have && m.amb_mode == RK_AMB_MEAN) ? pow(10.0, (double)v) : 0.0;
+#pragma unroll
+            for (u32 ww = 0; ww < 4; ww++) {  // pass 1 (:1139-1157 / :1198-1219)
+                if (have && w == ww) {
+                    const u32 c = Camb[x];
+                    Camb[x] = c + 1;
+                    if (m.amb_mode == RK_AMB_MEAN) {
+                        Samb[x] = (float)((double)Samb[x] + pw);
+                    } else {
+                        const float cur = Samb[x];
+                        Samb[x] = (c == 0 || v > cur) ? v : cur;
+                    }
+                }
+                wave_lds_fence();
+            }
+            bool own = false;  // pass 2 (:1161-1172 / :1223-1233): the first alternative that lists x folds it into S
+            u32 c_own = 0;
+            float samb_own = 0.0f;
+#pragma unroll
+            for (u32 ww = 0; ww < 4; ww++) {
+                if (have && w == ww) {
+                    const u32 c = Camb[x];
+                    if (c != 0) {
+                        own = true;
+                        c_own = c;
+                        samb_own = Samb[x];
+                        Camb[x] = 0;
+                        Samb[x] = 0.0f;
+                    }
+                }
+                wave_lds_fence();
+            }
+            if (own) {
+                const u32 old = S[x + 1];  // slot layout: branch x is word x + 1
+                const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+                float nw;
+                if (m.amb_mode == RK_AMB_MEAN) {
+                    const float missing = (float)(int)(W - c_own);
+                    const float pad = missing * P;
+                    const float tot = samb_own + pad;
+                    const float avg = tot / (float)(int)W;
+                    nw = (float)((double)base + (log10((double)avg) - (double)T));
+                } else {
+                    const float dd = samb_own - T;
+                    nw = base + dd;
+                }
+                S[x + 1] = __float_as_uint(nw);
+            }
+            wave_lds_fence();
+            return;
+        }
         if (maxlen <= 64) {
             u32 xb[4];
             float v[4];
