@@ -22,7 +22,7 @@
 #define RK_ROW_NT 0
 #endif
 #ifndef RK_ABLATE
-#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row (outputs are then wrong)
+#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate (outputs are then wrong)
 #endif
 #include "../../include/rappas_place.h"
 
@@ -1489,7 +1489,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                 if (cnt > 0) {
                     if (lane == 0) clist[cnt] = 0;  // sentinel: an empty row ends the cursor
                     wave_lds_fence();
-                    accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T);
+                    if (!(RK_ABLATE & 256)) accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T);
                     wave_lds_fence();
                     cnt = 0;
                 }
@@ -1529,7 +1529,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     if (__builtin_popcount(maskA) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP) {
                         const u32 p = __builtin_ctz(maskA);
                         const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
-                        amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT);
+                        if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT);
                     }
                     amb_b &= amb_b - 1;
                     p0 = na + 1;
