@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
             float v = 0.0f;
             if (w < W && e < ((u32)dw & DESC_LEN_MASK)) load_entry(a.db, dw, e, x, v);
             const bool have = x != 0xFFFFu;
-            const double pw = (have && m.amb_mode == RK_AMB_MEAN) ? pow(10.0, (double)v) : 0.0;
+            const double pw = (have && m.amb_mode == RK_AMB_MEAN) ? exp10((double)v) : 0.0;
 #pragma unroll
             for (u32 ww = 0; ww < 4; ww++) {  // pass 1 (:1139-1157 / :1198-1219)
                 if (have && w == ww) {
@@ -1347,7 +1347,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                     const u32 c = Camb[x];
                     Camb[x] = c + 1;
                     if (m.amb_mode == RK_AMB_MEAN) {
-                        Samb[x] = (float)((double)Samb[x] + pow(10.0, (double)v[w]));
+                        Samb[x] = (float)((double)Samb[x] + exp10((double)v[w]));
                     } else {
                         const float cur = Samb[x];
                         Samb[x] = (c == 0 || v[w] > cur) ? v[w] : cur;
@@ -1401,7 +1401,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 Camb[x] = c + 1;
                 if (m.amb_mode == RK_AMB_MEAN) {
                     // S_amb[x] += Math.pow(10, v)  (float += double, :1155)
-                    Samb[x] = (float)((double)Samb[x] + pow(10.0, (double)v));
+                    Samb[x] = (float)((double)Samb[x] + exp10((double)v));
                 } else {
                     float cur = Samb[x];
                     Samb[x] = (c == 0 || v > cur) ? v : cur;  // :1212-1217
