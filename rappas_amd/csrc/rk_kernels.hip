@@ -1464,6 +1464,8 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     const u32 k = a.db.k;
     const float T = a.db.T;
     const int cap = ASCII_LIST_CAP - 1;
+    const bool fit32 = a.db.rows_bytes < ROWS_FIT32_LIMIT;
+    const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     for (u32 i = lane; i < a.s_stride; i += 64) S[i] = S_UNTOUCHED;
     for (u32 i = lane; i < chunk; i += 64) { Samb[i] = 0.0f; Camb[i] = 0; }
     wave_lds_fence();
@@ -1485,13 +1487,35 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
             const u32 Q = R >= k ? R - k + 1 : 0;
             const float QT = (float)(int)Q * T;
             int cnt = 0;
+            bool any_long = false;  // a pending row of more than 64 entries (more than one chunk of this 64-lane group)
             auto flush = [&]() {
                 if (cnt > 0) {
+                    if (!SOA && fit32 && !any_long && !(RK_ABLATE & 256)) {
+                        // the usual case: every pending row is one chunk -> the buffer-addressed unit path of the packed kernel
+                        // (descriptors turned into unit items in place: every lane first reads its <= 3 descriptors)
+                        u64 dreg[3];
+#pragma unroll
+                        for (int t = 0; t < 3; t++) dreg[t] = ((int)lane + 64 * t < cnt) ? clist[lane + 64 * t] : 0ull;
+                        wave_lds_fence();
+                        u32 *items = (u32 *)clist;
+#pragma unroll
+                        for (int t = 0; t < 3; t++)
+                            if ((int)lane + 64 * t < cnt)
+                                items[lane + 64 * t] = ((u32)(dreg[t] >> DESC_LEN_BITS) * 8u) | ((((u32)dreg[t] & DESC_LEN_MASK) >> 4) - 1u);
+                        for (int i = cnt + (int)lane; i < cnt + 2 * RK_ASCII_RING; i += 64) items[i] = ITEM_FILLER;
+                        wave_lds_fence();
+                        if (a.db.mono) accumulate_units<64, RK_ASCII_RING, true>(S, items, cnt, lane, rows_rs, QT, T);
+                        else accumulate_units<64, RK_ASCII_RING, false>(S, items, cnt, lane, rows_rs, QT, T);
+                        wave_lds_fence();
+                        cnt = 0;
+                        return;
+                    }
                     if (lane == 0) clist[cnt] = 0;  // sentinel: an empty row ends the cursor
                     wave_lds_fence();
                     if (!(RK_ABLATE & 256)) accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T);
                     wave_lds_fence();
                     cnt = 0;
+                    any_long = false;
                 }
             };
             for (u32 j0 = 0; j0 < Q; j0 += 64) {
@@ -1520,6 +1544,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     if (cnt + nh > cap) flush();
                     if ((hb >> lane) & 1ull) clist[cnt + __builtin_popcountll(hb & ((1ull << lane) - 1))] = desc;
                     cnt += nh;
+                    any_long = any_long || __any(((hb >> lane) & 1ull) && ((u32)desc & DESC_LEN_MASK) > 64u);
                     if (na >= 64) break;
                     flush();  // everything before the ambiguous k-mer must be applied first
                     const u32 maskA = (u32)__builtin_amdgcn_readlane((int)ambmask, (int)na);
