@@ -25,7 +25,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5mini", "C5s"])
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5mini", "C5s", "C5m"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's count)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per read (0=auto, 8/16/32/64)")
     ap.add_argument("--table", default="auto", choices=["auto", "direct", "direct8", "hash"])

@@ -23,7 +23,10 @@ struct __attribute__((aligned(8))) Entry {
     u32 branch;
     float score;
 };
-constexpr u32 ROWS_FIT32_LIMIT = 0xFFFF0000u;  // blobs below this use 32-bit offsets (ITEM_FILLER must stay outside the buffer)
+#ifndef RK_FIT32_LIMIT
+#define RK_FIT32_LIMIT 0xFFFF0000u  // (developer builds lower it to time the 64-bit-offset kernels on small databases)
+#endif
+constexpr u32 ROWS_FIT32_LIMIT = RK_FIT32_LIMIT;  // blobs below this use 32-bit offsets (ITEM_FILLER must stay outside the buffer)
 constexpr u32 ROW_UNIT = 16;  // entries per 128-byte unit; rows are unit-aligned and padded to whole units
 
 // k-mer -> row lookup flavours (template parameter of the kernels)

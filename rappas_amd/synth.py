@@ -22,6 +22,8 @@ CONFIGS = {
     # C5-shaped per-read work (19 999 branches, rows of ~2 600 entries, 250 bp => H ~ 4.7e5 entries/read) with a smaller
     # key space (k=8) so that the DB is ~1 GB instead of 200 GB: beyond the Infinity Cache, i.e. HBM-bound like C5
     "C5s": (4, 8, 10_000, 49_152, 127_795_200, 250, 200_000),
+    # the same per-read work against a 12 GB database (k=10 at C2's key coverage, rows of ~2 600): 64-bit row offsets
+    "C5m": (4, 10, 10_000, 786_432, 2_044_723_200, 250, 100_000),
 }
 
 
