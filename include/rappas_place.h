@@ -142,8 +142,9 @@ int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_
 int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                          const uint64_t *seq_off, rk_result *out, rk_counters *counters);
 
-/* Page-locked host memory for the buffers handed to rk_place_batch: with pinned input/output the host path runs at
- * ~1.3e8 reads/s (C2, 150 bp) instead of ~6e7 with pageable memory.  A JVM can wrap it with NewDirectByteBuffer. */
+/* Page-locked host memory for the buffers handed to rk_place_batch: the DMA then reads / writes them directly.  Pageable
+ * buffers work too (they are staged through page-locked memory inside the library, ~1.2e8 reads/s either way on C2); pinned
+ * ones save the host threads that staging keeps busy.  A JVM can wrap the allocation with NewDirectByteBuffer. */
 void *rk_host_alloc(uint64_t bytes);
 void rk_host_free(void *p);
 

@@ -144,12 +144,51 @@ struct GrowBuf {
 };
 }  // namespace
 
+namespace {
+struct PinBuf {  // page-locked host staging, grow-only
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return RK_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        return RK_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// memcpy split over a few host threads: one thread moves ~10 GB/s, the PCIe link five times that
+void parallel_copy(void *dst, const void *src, size_t bytes) {
+    const size_t min_part = 4u << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t parts = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 6u), bytes / min_part);
+    if (parts <= 1) { if (bytes) memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < parts; i++) {
+        const size_t a = bytes * i / parts, b = bytes * (i + 1) / parts;
+        th.emplace_back([=]() { memcpy((char *)dst + a, (const char *)src + a, b - a); });
+    }
+    memcpy(dst, src, bytes / parts);
+    for (std::thread &t : th) t.join();
+}
+}  // namespace
+
 struct rk_workspace {
     GrowBuf ascii, off, packed, lens, flags, nrows, branch, score, lwr, oflags;
+    // page-locked staging for callers that hand over pageable memory (a JVM heap array, a numpy array): copies to / from
+    // it run on a few host threads, the DMA itself is then asynchronous and overlaps the other workspace's chunk
+    PinBuf h_ascii, h_off, h_nrows, h_branch, h_score, h_lwr, h_oflags;
+    bool pending = false;       // results of the last chunk are still in the staging buffers
+    uint64_t pend_r0 = 0, pend_n = 0;
     hipStream_t stream = nullptr;
-    std::vector<uint64_t> host_off;
     void release() {
         for (GrowBuf *b : {&ascii, &off, &packed, &lens, &flags, &nrows, &branch, &score, &lwr, &oflags}) b->release();
+        for (PinBuf *b : {&h_ascii, &h_off, &h_nrows, &h_branch, &h_score, &h_lwr, &h_oflags}) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -901,6 +940,25 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
     const uint64_t max_chunk_reads = 1ull << 19, max_chunk_bytes = 128ull << 20;
     for (rk_workspace &w : db->ws)
         if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    // Caller buffers from rk_host_alloc (or otherwise page-locked) are the DMA's source / target directly; pageable ones
+    // (the usual case behind JNI) go through page-locked staging with threaded copies
+    auto is_pinned = [](const void *ptr) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool in_pinned = is_pinned(seq_ascii);
+    const bool out_pinned = is_pinned(out->n_rows) && is_pinned(out->branch) && is_pinned(out->score) && is_pinned(out->lwr) && is_pinned(out->flags);
+    auto drain = [&](rk_workspace &w) {  // staged results of the workspace's last chunk -> the caller's arrays
+        if (!w.pending) return;
+        const uint64_t a0 = w.pend_r0, m = w.pend_n;
+        memcpy(out->n_rows + a0, w.h_nrows.p, m);
+        parallel_copy(out->branch + a0 * K, w.h_branch.p, m * K * 2);
+        parallel_copy(out->score + a0 * K, w.h_score.p, m * K * 4);
+        parallel_copy(out->lwr + a0 * K, w.h_lwr.p, m * K * 8);
+        memcpy(out->flags + a0, w.h_oflags.p, m * 4);
+        w.pending = false;
+    };
     uint64_t r0 = 0;
     unsigned chunk_no = 0;
     int status = RK_OK;
@@ -919,8 +977,7 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
         // the workspace was last used two chunks ago: its downloads must have landed before it is overwritten
         hipError_t he = hipStreamSynchronize(s);
         if (he != hipSuccess) { status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)); break; }
-        w.host_off.resize(n + 1);
-        for (uint64_t i = 0; i <= n; i++) w.host_off[i] = seq_off[r0 + i] - seq_off[r0];
+        drain(w);
 #define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
 #define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
         WS_TRY(w.ascii.reserve(nbytes));
@@ -933,8 +990,19 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
         WS_TRY(w.score.reserve(n * K * 4));
         WS_TRY(w.lwr.reserve(n * K * 8));
         WS_TRY(w.oflags.reserve(n * 4));
-        if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
-        WS_HIP(hipMemcpyAsync(w.off.p, w.host_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        WS_TRY(w.h_off.reserve((n + 1) * 8));
+        {
+            uint64_t *ho = w.h_off.as<uint64_t>();
+            for (uint64_t i = 0; i <= n; i++) ho[i] = seq_off[r0 + i] - seq_off[r0];
+        }
+        if (in_pinned) {
+            if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
+        } else if (nbytes) {
+            WS_TRY(w.h_ascii.reserve(nbytes));
+            parallel_copy(w.h_ascii.p, seq_ascii + seq_off[r0], nbytes);
+            WS_HIP(hipMemcpyAsync(w.ascii.p, w.h_ascii.p, nbytes, hipMemcpyHostToDevice, s));
+        }
+        WS_HIP(hipMemcpyAsync(w.off.p, w.h_off.p, (n + 1) * 8, hipMemcpyHostToDevice, s));
         WS_TRY(rk_pack_reads_device(db, n, w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), wpr, w.packed.as<uint32_t>(),
                                     w.lens.as<uint32_t>(), w.flags.as<uint32_t>(), s));
         {
@@ -942,11 +1010,25 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
             WS_TRY(rk_place_packed_device(db, p, n, w.packed.as<uint32_t>(), wpr, w.lens.as<uint32_t>(), 0, w.flags.as<uint32_t>(),
                                           w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), &dres, s));
         }
-        WS_HIP(hipMemcpyAsync(out->n_rows + r0, w.nrows.p, n, hipMemcpyDeviceToHost, s));
-        WS_HIP(hipMemcpyAsync(out->branch + r0 * K, w.branch.p, n * K * 2, hipMemcpyDeviceToHost, s));
-        WS_HIP(hipMemcpyAsync(out->score + r0 * K, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
-        WS_HIP(hipMemcpyAsync(out->lwr + r0 * K, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
-        WS_HIP(hipMemcpyAsync(out->flags + r0, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (out_pinned) {
+            WS_HIP(hipMemcpyAsync(out->n_rows + r0, w.nrows.p, n, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(out->branch + r0 * K, w.branch.p, n * K * 2, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(out->score + r0 * K, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(out->lwr + r0 * K, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(out->flags + r0, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
+        } else {
+            WS_TRY(w.h_nrows.reserve(n));
+            WS_TRY(w.h_branch.reserve(n * K * 2));
+            WS_TRY(w.h_score.reserve(n * K * 4));
+            WS_TRY(w.h_lwr.reserve(n * K * 8));
+            WS_TRY(w.h_oflags.reserve(n * 4));
+            WS_HIP(hipMemcpyAsync(w.h_nrows.p, w.nrows.p, n, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(w.h_branch.p, w.branch.p, n * K * 2, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(w.h_score.p, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(w.h_lwr.p, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
+            WS_HIP(hipMemcpyAsync(w.h_oflags.p, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
+            w.pending = true; w.pend_r0 = r0; w.pend_n = n;
+        }
 #undef WS_TRY
 #undef WS_HIP
         r0 = r1;
@@ -957,6 +1039,8 @@ done:
         if (w.stream) {
             hipError_t he = hipStreamSynchronize(w.stream);
             if (he != hipSuccess && status == RK_OK) status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he));
+            if (status == RK_OK) drain(w);
+            w.pending = false;
         }
     if (status != RK_OK) return status;
     for (uint64_t r = 0; r < n_reads; r++) {
