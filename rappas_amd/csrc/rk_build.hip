@@ -113,6 +113,7 @@ struct Explorer {  // WordExplorer_v3 fields (:37-55) of the lane's current expl
     u64 code;
     u64 visits;
     u64 tuples;
+    int firstJump;  // idxOfFirstJump (:49)
 };
 
 // exploreWords(site, rank) at depth `depth` for a node with exactly L levels below it (L == 0: a leaf), without gap jumps:
@@ -139,6 +140,46 @@ __device__ __forceinline__ void explore_tail(const BuildArgs &a, volatile WaveCu
         for (int j2 = 0; j2 < (int)a.n_states; j2++) {                      // :147
             if (e.bound && e.boundK == depth + 1) break;                    // :148-150
             explore_tail<(L > 0 ? L - 1 : 0)>(a, wc, e, site + 1, j2, depth + 1, node_base, branch, lane);
+        }
+        e.sum = (float)((double)e.sum - (double)p);                         // :198
+    }
+}
+
+// The same with gap jumps (:161-186): after the plain child at site + 1, the children at site + 1 + len for every gap interval
+// that starts at site + 1 -- all of them, or (limitTo1Jump) only while no jump has been taken since the explorer's current first
+// state (`firstJump` is sticky, exactly like idxOfFirstJump).  Jumped-to sites are arbitrary, so every visit loads its cell.
+template <int L>
+__device__ __forceinline__ void explore_tail_gaps(const BuildArgs &a, volatile WaveCursor *wc, Explorer &e, int site, int rank,
+                                                  int depth, size_t node_base, u32 branch, u32 lane) {
+    if (site > (int)a.n_sites - 1) return;                                  // :109-111
+    if (depth == 0) e.firstJump = -1;                                       // :113-115
+    const size_t at = node_base + (size_t)site * a.n_states + (size_t)rank;
+    const u32 st = a.states[at];
+    const float p = a.pp[at];
+    e.visits++;
+    const u32 sh = a.bits * (u32)depth;
+    e.code = (e.code & ~(((1ull << a.bits) - 1) << sh)) | ((u64)st << sh);  // :117
+    e.sum = (float)((double)e.sum + (double)p);                             // :119
+    e.bound = e.sum < a.T;                                                  // :120
+    if (e.bound) e.boundK = depth;                                          // :121-123
+    if (L == 0) {
+        append_tuples(a, wc, !e.bound, (e.code << 16) | branch, e.sum, lane, e.tuples);  // :128-138
+        e.sum = (float)((double)e.sum - (double)p);                         // :141
+        return;
+    } else {
+        for (int j2 = 0; j2 < (int)a.n_states; j2++) {                      // :147
+            if (e.bound && e.boundK == depth + 1) break;                    // :148-150
+            explore_tail_gaps<(L > 0 ? L - 1 : 0)>(a, wc, e, site + 1, j2, depth + 1, node_base, branch, lane);
+            if (site < (int)a.n_sites - 1) {                                // :161
+                const int g0 = (int)a.gap_off[site + 1], g1 = (int)a.gap_off[site + 2];
+                if (g1 > g0) {                                              // :163
+                    bool jump = !a.limit1;
+                    if (a.limit1 && e.firstJump == -1) { e.firstJump = site; jump = true; }  // :174-175
+                    if (jump)
+                        for (int g = g0; g < g1; g++)
+                            explore_tail_gaps<(L > 0 ? L - 1 : 0)>(a, wc, e, (site + 1) + a.gap_len[g], j2, depth + 1, node_base, branch, lane);
+                }
+            }
         }
         e.sum = (float)((double)e.sum - (double)p);                         // :198
     }
@@ -264,7 +305,7 @@ __device__ __forceinline__ void run_tail20(const BuildArgs &a, volatile WaveCurs
 
 // INL = levels of the recursion below a node that explore_tail runs in registers (the node itself included: 1 + NS + ... +
 // NS^INL visits per transition).
-template <int INL, int VEC>  // VEC: 4 / 20 = register-resident site rows for that many states, 0 = generic
+template <int INL, int VEC, bool GAPS>  // VEC: 4 / 20 = register-resident site rows for that many states, 0 = generic
 __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(BuildArgs a) {
     __shared__ Frames frames[BUILD_WAVES_PER_BLOCK];
     __shared__ WaveCursor cursors[BUILD_WAVES_PER_BLOCK];
@@ -364,10 +405,19 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
         bool emit = false;
         float emit_score = 0.0f;
         const int below = k - 1 - cd;  // levels below the called node
-        if (call && !a.do_gap && below <= INL) {
+        if (call && (GAPS || !a.do_gap) && below <= INL) {
             if (cd == 0) firstJump = -1;
-            Explorer e{sum, bound, boundK, code, visits, tuples};
-            if (V4) {
+            Explorer e{sum, bound, boundK, code, visits, tuples, firstJump};
+            if (GAPS) {
+                switch (below) {
+                case 0: explore_tail_gaps<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 1: explore_tail_gaps<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 2: if (INL >= 2) explore_tail_gaps<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                case 3: if (INL >= 3) explore_tail_gaps<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+                default: break;
+                }
+                firstJump = e.firstJump;
+            } else if (V4) {
                 switch (below) {
                 case 0: run_tail4<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
                 case 1: run_tail4<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
@@ -578,9 +628,10 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
             const int vec = getenv("RK_BUILD_NO_VEC") ? 0 : (d->n_states == 4 ? 4 : (d->n_states == 20 ? 20 : 0));
 #define RK_LAUNCH_EXPLORE(I)                                                                                \
     do {                                                                                                    \
-        if (vec == 4) hipLaunchKernelGGL((explore_kernel<I, 4>), grid, block, 0, 0, a);                     \
-        else if (vec == 20) hipLaunchKernelGGL((explore_kernel<I, 20>), grid, block, 0, 0, a);              \
-        else hipLaunchKernelGGL((explore_kernel<I, 0>), grid, block, 0, 0, a);                              \
+        if (a.do_gap) hipLaunchKernelGGL((explore_kernel<(I > 2 ? 2 : I), 0, true>), grid, block, 0, 0, a); \
+        else if (vec == 4) hipLaunchKernelGGL((explore_kernel<I, 4, false>), grid, block, 0, 0, a);         \
+        else if (vec == 20) hipLaunchKernelGGL((explore_kernel<I, 20, false>), grid, block, 0, 0, a);       \
+        else hipLaunchKernelGGL((explore_kernel<I, 0, false>), grid, block, 0, 0, a);                       \
     } while (0)
             if (inl >= 3) RK_LAUNCH_EXPLORE(3);
             else if (inl == 2) RK_LAUNCH_EXPLORE(2);
