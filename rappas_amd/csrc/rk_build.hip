@@ -405,19 +405,29 @@ __global__ void __launch_bounds__(64 * BUILD_WAVES_PER_BLOCK) explore_kernel(Bui
         bool emit = false;
         float emit_score = 0.0f;
         const int below = k - 1 - cd;  // levels below the called node
-        if (call && (GAPS || !a.do_gap) && below <= INL) {
-            if (cd == 0) firstJump = -1;
+        if (cd == 0 && call) firstJump = -1;  // :113-115 (a call at depth 0 beyond the alignment cannot happen: pos < n_sites)
+        // one-jump mode: once the explorer has jumped for its current first state, the rest of that first state's subtree is
+        // explored exactly as without gap jumps (idxOfFirstJump stays set): the register-resident tails apply again
+        // ... and a subtree none of whose inner sites is followed by the start of a gap interval cannot jump in either mode
+        bool jumps_possible = GAPS && call && below <= INL && !(a.limit1 && firstJump != -1);
+        if (jumps_possible) {
+            const int s_lo = min(ci + 1, S), s_hi = min(ci + below, S - 1) + 1;  // intervals starting in [ci + 1, ci + below]
+            jumps_possible = s_hi > s_lo && a.gap_off[s_hi] > a.gap_off[s_lo];
+        }
+        constexpr int INL_GAPS = INL < 2 ? INL : 2;
+        if (call && jumps_possible && below <= INL_GAPS) {
             Explorer e{sum, bound, boundK, code, visits, tuples, firstJump};
-            if (GAPS) {
-                switch (below) {
-                case 0: explore_tail_gaps<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-                case 1: explore_tail_gaps<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-                case 2: if (INL >= 2) explore_tail_gaps<(INL >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-                case 3: if (INL >= 3) explore_tail_gaps<(INL >= 3 ? 3 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
-                default: break;
-                }
-                firstJump = e.firstJump;
-            } else if (V4) {
+            switch (below) {
+            case 0: explore_tail_gaps<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            case 1: explore_tail_gaps<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            case 2: if (INL_GAPS >= 2) explore_tail_gaps<(INL_GAPS >= 2 ? 2 : 0)>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
+            default: break;
+            }
+            sum = e.sum; bound = e.bound; boundK = e.boundK; code = e.code; visits = e.visits; tuples = e.tuples;
+            firstJump = e.firstJump;
+        } else if (call && !jumps_possible && below <= INL) {
+            Explorer e{sum, bound, boundK, code, visits, tuples, firstJump};
+            if (V4) {
                 switch (below) {
                 case 0: run_tail4<0>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
                 case 1: run_tail4<1>(a, wc, e, ci, cj, cd, node_base, branch, lane); break;
@@ -628,8 +638,11 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
             const int vec = getenv("RK_BUILD_NO_VEC") ? 0 : (d->n_states == 4 ? 4 : (d->n_states == 20 ? 20 : 0));
 #define RK_LAUNCH_EXPLORE(I)                                                                                \
     do {                                                                                                    \
-        if (a.do_gap) hipLaunchKernelGGL((explore_kernel<(I > 2 ? 2 : I), 0, true>), grid, block, 0, 0, a); \
-        else if (vec == 4) hipLaunchKernelGGL((explore_kernel<I, 4, false>), grid, block, 0, 0, a);         \
+        if (a.do_gap) {                                                                                     \
+            if (vec == 4) hipLaunchKernelGGL((explore_kernel<I, 4, true>), grid, block, 0, 0, a);           \
+            else if (vec == 20) hipLaunchKernelGGL((explore_kernel<I, 20, true>), grid, block, 0, 0, a);    \
+            else hipLaunchKernelGGL((explore_kernel<I, 0, true>), grid, block, 0, 0, a);                    \
+        } else if (vec == 4) hipLaunchKernelGGL((explore_kernel<I, 4, false>), grid, block, 0, 0, a);       \
         else if (vec == 20) hipLaunchKernelGGL((explore_kernel<I, 20, false>), grid, block, 0, 0, a);       \
         else hipLaunchKernelGGL((explore_kernel<I, 0, false>), grid, block, 0, 0, a);                       \
     } while (0)
