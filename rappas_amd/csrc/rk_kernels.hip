@@ -1256,7 +1256,8 @@ struct AmbArgs {
 // does not fit one window), then folded into S.
 template <int BITS, int TM>
 __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &m, u32 *S, float *Samb, u32 *Camb,
-                                             u32 chunk, u64 code, u32 p, u32 cls, u32 lane, float QT) {
+                                             u32 chunk, u64 code, u32 p, u32 cls, u32 lane, float QT, bool have_pre,
+                                             const u64 (&pre)[4]) {
     const u32 nb = a.db.n_branches;
     const float T = a.db.T, P = a.db.P;
     const u32 W = m.alt_count[cls];
@@ -1266,8 +1267,10 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
         // per-branch updates still run alternative by alternative, in the reference's order
         u64 d[4];
 #pragma unroll
-        for (int w = 0; w < 4; w++)
-            d[w] = ((u32)w < W) ? lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p))) : 0ull;
+        for (int w = 0; w < 4; w++) {
+            if (have_pre) d[w] = pre[w];  // looked up with the block's other ambiguous positions (place_ascii_kernel)
+            else d[w] = ((u32)w < W) ? lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p))) : 0ull;
+        }
         const u32 maxlen = max(max((u32)d[0] & DESC_LEN_MASK, (u32)d[1] & DESC_LEN_MASK),
                                max((u32)d[2] & DESC_LEN_MASK, (u32)d[3] & DESC_LEN_MASK));
         if (maxlen <= 16) {
@@ -1533,6 +1536,22 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                 u64 desc = 0;
                 if (inr && ambmask == 0) desc = lookup_desc<BITS, TM>(a.db, code);
                 const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
+                // one ambiguous character puts k consecutive positions on the ambiguity path: their alternatives (<= 4 each for
+                // DNA) are looked up here for all of them at once, one lane per position, instead of one position at a time
+                u64 alt_d[4] = {0ull, 0ull, 0ull, 0ull};
+                const bool one_amb = inr && __builtin_popcount(ambmask) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP;
+                bool pre_ok = false;
+                if (one_amb) {
+                    const u32 p = __builtin_ctz(ambmask);
+                    const u32 cls = m.char_table[s[j + p]] & 0x7F;
+                    const u32 W = m.alt_count[cls];
+                    if (W <= 4) {
+                        pre_ok = true;
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            if ((u32)w < W) alt_d[w] = lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p)));
+                    }
+                }
                 u64 amb_b = __ballot(inr && ambmask != 0);
                 const u64 hit_b = __ballot(hit);
                 u32 p0 = 0;
@@ -1554,7 +1573,13 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     if (__builtin_popcount(maskA) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP) {
                         const u32 p = __builtin_ctz(maskA);
                         const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
-                        if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT);
+                        const bool have_pre = __builtin_amdgcn_readlane((int)pre_ok, (int)na) != 0;
+                        u64 pre[4];
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            pre[w] = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(alt_d[w] >> 32), (int)na) << 32) |
+                                     (u32)__builtin_amdgcn_readlane((int)(u32)alt_d[w], (int)na);
+                        if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT, have_pre, pre);
                     }
                     amb_b &= amb_b - 1;
                     p0 = na + 1;
