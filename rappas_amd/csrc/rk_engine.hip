@@ -363,42 +363,73 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     // padding / reserved line 0: raw-id images (large trees) skip on 0xFFFF, slot-offset images update scratch slot 0
     try { blob.assign(blob_bytes / 8, indexed ? Entry{0xFFFFFFFFu, 0.0f} : Entry{0u, 0.0f}); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM for %llu-byte row blob", (unsigned long long)blob_bytes); }
     {
-        std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
-        for (uint64_t r = 0; r < n_keys; r++) {
-            uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
-            Entry *ep = blob.data() + (desc[r] >> DESC_LEN_BITS);
+        // validation + fill, rows are independent: a few host threads over contiguous key ranges (6e8 entries took 14 s on one)
+        struct RowErr { int kind = 0; uint64_t r = ~0ull; uint32_t x = 0; };
+        auto fill = [&](uint64_t r_lo, uint64_t r_hi, RowErr &err, bool &mono) {
+            std::vector<uint32_t> stamp(d->n_branches, 0xFFFFFFFFu);
             std::vector<Entry> tmp;
-            if (indexed) { tmp.resize(len); ep = tmp.data(); }
-            for (uint64_t i = 0; i < len; i++) {
-                uint16_t x = d->branch_ids[b + i];
-                float v = d->scores[b + i];
-                if (x >= d->n_branches) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u >= n_branches in row %llu", x, (unsigned long long)r);
-                if (stamp[x] == (uint32_t)r) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", x, (unsigned long long)r);
-                stamp[x] = (uint32_t)r;
-                if (!std::isfinite(v)) return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)r);
-                if (!(v >= d->thr_log10)) img.mono = false;
-                ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
-                ep[i].score = v;
-            }
-            if (indexed) {
-                std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
-                unsigned char *row = (unsigned char *)(blob.data() + (desc[r] >> DESC_LEN_BITS));
-                const uint64_t lenp = (uint32_t)desc[r] & DESC_LEN_MASK;
-                uint16_t *split = (uint16_t *)(row - 64);  // the 64-byte line in front of the row
-                uint16_t *bp = (uint16_t *)row;
-                float *sp = (float *)(row + 2 * lenp);
-                uint64_t e = 0;
-                for (uint32_t i = 1; i <= 32; i++) {
-                    const uint32_t bound = (uint32_t)(((uint64_t)i * d->n_branches) / 32);
-                    while (e < len && ep[e].branch < bound) e++;
-                    split[i - 1] = (uint16_t)e;
+            for (uint64_t r = r_lo; r < r_hi; r++) {
+                uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
+                Entry *ep = blob.data() + (desc[r] >> DESC_LEN_BITS);
+                if (indexed) { tmp.resize(len); ep = tmp.data(); }
+                for (uint64_t i = 0; i < len; i++) {
+                    uint16_t x = d->branch_ids[b + i];
+                    float v = d->scores[b + i];
+                    if (x >= d->n_branches) { err = {1, r, x}; return; }
+                    if (stamp[x] == (uint32_t)r) { err = {2, r, x}; return; }
+                    stamp[x] = (uint32_t)r;
+                    if (!std::isfinite(v)) { err = {3, r, x}; return; }
+                    if (!(v >= d->thr_log10)) mono = false;
+                    ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
+                    ep[i].score = v;
                 }
-                for (uint64_t i = 0; i < lenp; i++) {
-                    bp[i] = i < len ? (uint16_t)ep[i].branch : (uint16_t)0xFFFFu;  // padding = skip entries
-                    sp[i] = i < len ? ep[i].score : 0.0f;
+                if (indexed) {
+                    std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
+                    unsigned char *row = (unsigned char *)(blob.data() + (desc[r] >> DESC_LEN_BITS));
+                    const uint64_t lenp = (uint32_t)desc[r] & DESC_LEN_MASK;
+                    uint16_t *split = (uint16_t *)(row - 64);  // the 64-byte line in front of the row
+                    uint16_t *bp = (uint16_t *)row;
+                    float *sp = (float *)(row + 2 * lenp);
+                    uint64_t e = 0;
+                    for (uint32_t i = 1; i <= 32; i++) {
+                        const uint32_t bound = (uint32_t)(((uint64_t)i * d->n_branches) / 32);
+                        while (e < len && ep[e].branch < bound) e++;
+                        split[i - 1] = (uint16_t)e;
+                    }
+                    for (uint64_t i = 0; i < lenp; i++) {
+                        bp[i] = i < len ? (uint16_t)ep[i].branch : (uint16_t)0xFFFFu;  // padding = skip entries
+                        sp[i] = i < len ? ep[i].score : 0.0f;
+                    }
                 }
             }
+        };
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned T = n_entries > (1u << 22) ? std::max(1u, std::min(hw ? hw : 1u, 16u)) : 1u;
+        std::vector<RowErr> errs(T);
+        std::vector<char> monos(T, 1);
+        std::vector<std::thread> th;
+        // ranges of (roughly) equal entry counts
+        std::vector<uint64_t> cut(T + 1, n_keys);
+        cut[0] = 0;
+        for (unsigned t = 1; t < T; t++) {
+            const uint64_t want = n_entries * t / T;
+            cut[t] = (uint64_t)(std::lower_bound(d->row_offsets, d->row_offsets + n_keys, want) - d->row_offsets);
         }
+        for (unsigned t = 0; t < T; t++) {
+            auto job = [&, t]() { bool mono = true; fill(cut[t], cut[t + 1], errs[t], mono); monos[t] = mono ? 1 : 0; };
+            if (t + 1 < T) th.emplace_back(job); else job();
+        }
+        for (std::thread &x : th) x.join();
+        const RowErr *first = nullptr;
+        for (const RowErr &e : errs)
+            if (e.kind && (!first || e.r < first->r)) first = &e;
+        if (first) {
+            if (first->kind == 1) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u >= n_branches in row %llu", first->x, (unsigned long long)first->r);
+            if (first->kind == 2) return fail(RK_ERR_INVALID, "rk_db_create: branch id %u repeated inside row %llu", first->x, (unsigned long long)first->r);
+            return fail(RK_ERR_INVALID, "rk_db_create: non-finite score in row %llu", (unsigned long long)first->r);
+        }
+        for (char mflag : monos)
+            if (!mflag) img.mono = false;
     }
 
     // ---- table ----
