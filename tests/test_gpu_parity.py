@@ -370,3 +370,32 @@ def test_randomised_configurations(seed):
         # the only configurations the engine may refuse: lane groups narrower than keep_at_most, or a fixed width on a large-tree image
         assert ("lanes_per_read" in str(e) or "keep_at_most" in str(e)), e
         pytest.skip(f"configuration refused as documented: {e}")
+
+
+@pytest.mark.parametrize("convert", [False, True])
+def test_selenocysteine_and_pyrrolysine_follow_the_convertUO_switch(convert):
+    """AAStates.java:118-123: with --convertUO a database treats U as C and O as L; without it both are unsupported characters."""
+    sdb = synth.make_config_db("C4", scale=0.2)
+    seq, off = synth.make_reads(20, 600, 80, seed=3)
+    seq = seq.copy()
+    rng = np.random.default_rng(2)
+    for r in range(0, 600, 3):  # every third read gets a U or an O (either case)
+        pos = int(off[r]) + int(rng.integers(0, 80))
+        seq[pos] = ord("UuOo"[int(rng.integers(0, 4))])
+    db = ra.PhyloKmerDB.from_synth(sdb, convert_uo=convert)
+    odb = O.OracleDB.from_synth(sdb, convert_uo=convert)
+    try:
+        got = ra.PlacementProcess(db).processQueries(seq, off)
+        ref = odb.place(seq, off)
+        compare_with_oracle(got, ref, odb, seq, off)
+        n_bad = int(((got.flags & ra.RK_FLAG_BAD_CHAR) != 0).sum())
+        assert n_bad == (0 if convert else 200)
+        # with the switch on, the reads place exactly as if C / L had been written
+        if convert:
+            plain = seq.copy()
+            for a, b in ((ord("U"), ord("C")), (ord("u"), ord("C")), (ord("O"), ord("L")), (ord("o"), ord("L"))):
+                plain[plain == a] = b
+            same = ra.PlacementProcess(db).processQueries(plain, off)
+            assert np.array_equal(same.branch, got.branch) and np.array_equal(same.score.view(np.uint32), got.score.view(np.uint32))
+    finally:
+        db.close()
