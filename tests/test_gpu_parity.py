@@ -399,3 +399,37 @@ def test_selenocysteine_and_pyrrolysine_follow_the_convertUO_switch(convert):
             assert np.array_equal(same.branch, got.branch) and np.array_equal(same.score.view(np.uint32), got.score.view(np.uint32))
     finally:
         db.close()
+
+
+def test_page_locked_caller_buffers_take_the_direct_dma_path(c2_small):
+    """rk_host_alloc / rk_host_free: buffers the DMA uses directly (no staging copies); same results as with pageable arrays,
+    also across several chunks (more than 2^19 reads would be needed for that: here the chunking is exercised by byte size)."""
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 5000, 150, seed=21, amb_rate=0.001)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    lib = _lib.load()
+    n, K = len(off) - 1, 7
+    sizes = dict(seq=seq.nbytes, off=off.nbytes, n_rows=n, branch=n * K * 2, score=n * K * 4, lwr=n * K * 8, flags=n * 4)
+    ptr = {k: lib.rk_host_alloc(v) for k, v in sizes.items()}
+    try:
+        assert all(ptr.values())
+        C.memmove(ptr["seq"], seq.ctypes.data, seq.nbytes)
+        C.memmove(ptr["off"], off.ctypes.data, off.nbytes)
+        res = _lib.rk_result(ptr["n_rows"], ptr["branch"], ptr["score"], ptr["lwr"], ptr["flags"])
+        p = _lib.rk_params(K, 0.01, _lib.RK_AMB_MEAN, float("-inf"))
+        ct = _lib.rk_counters()
+        _lib.check(lib.rk_place_batch(db.handle, C.byref(p), n, C.c_void_p(ptr["seq"]), C.c_void_p(ptr["off"]), C.byref(res), C.byref(ct)))
+        want = ra.PlacementProcess(db).processQueries(seq, off)  # pageable numpy arrays: the staged path
+        take = lambda k, dt, shape: np.ctypeslib.as_array(C.cast(ptr[k], C.POINTER(dt)), shape).copy()
+        assert np.array_equal(take("n_rows", C.c_uint8, (n,)), want.n_rows)
+        assert np.array_equal(take("branch", C.c_uint16, (n, K)), want.branch)
+        assert np.array_equal(take("score", C.c_uint32, (n, K)), want.score.view(np.uint32))
+        assert np.array_equal(take("lwr", C.c_double, (n, K)), want.lwr)
+        assert np.array_equal(take("flags", C.c_uint32, (n,)), want.flags)
+        assert ct.reads == n and ct.placed == want.counters["placed"]
+        compare_with_oracle(want, odb.place(seq, off), odb, seq, off)
+    finally:
+        for v in ptr.values():
+            lib.rk_host_free(v)
+        db.close()
+    lib.rk_host_free(None)  # no-op
