@@ -433,3 +433,33 @@ def test_page_locked_caller_buffers_take_the_direct_dma_path(c2_small):
             lib.rk_host_free(v)
         db.close()
     lib.rk_host_free(None)  # no-op
+
+
+def test_host_path_across_chunk_boundaries():
+    """rk_place_batch cuts a batch into chunks of 2^19 reads on two alternating workspaces (staged uploads / downloads): 1.3e6
+    short reads = three chunks; checked against the oracle around both boundaries and at the ends, and for order independence."""
+    sdb = synth.make_config_db("C1")
+    odb = O.OracleDB.from_synth(sdb)
+    n = 1_300_000
+    seq, off = synth.make_reads(4, n, 40, seed=5, amb_rate=0.0005, var_len=12)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    try:
+        got = ra.PlacementProcess(db).processQueries(seq, off)
+        assert got.counters["reads"] == n
+        for lo in (0, (1 << 19) - 300, (2 << 19) - 300, n - 600):
+            hi = lo + 600
+            sl = slice(lo, hi)
+            part = ra.Placements(got.n_rows[sl], got.branch[sl], got.score[sl], got.lwr[sl], got.flags[sl], {})
+            s0 = int(off[lo])
+            sub_seq, sub_off = seq[s0:int(off[hi])], off[lo:hi + 1] - off[lo]
+            compare_with_oracle(part, odb.place(sub_seq, sub_off), odb, sub_seq, sub_off)
+        # the same reads in reverse order give the same rows
+        order = np.arange(n - 1, -1, -1)
+        lens = np.diff(off.astype(np.int64))
+        roff = np.zeros(n + 1, np.uint64); roff[1:] = np.cumsum(lens[order])
+        idx = np.repeat(off[:-1].astype(np.int64)[order] - roff[:-1].astype(np.int64), lens[order]) + np.arange(int(roff[-1]))
+        rev = ra.PlacementProcess(db).processQueries(seq[idx], roff)
+        assert np.array_equal(rev.branch[::-1], got.branch) and np.array_equal(rev.score[::-1].view(np.uint32), got.score.view(np.uint32))
+        assert np.array_equal(rev.flags[::-1], got.flags)
+    finally:
+        db.close()
