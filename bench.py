@@ -25,7 +25,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5mini", "C5s", "C5m"])
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "C5mini", "C5s", "C5m"],
+                    help="C2 = the configuration BASELINE's metric is quoted on (default); C3 = C2's DB with 1.25e8 reads per GPU "
+                         "(1e9 reads over 8 GPUs); C5 = 10k-leaf tree, k=12, ~200 GB DB generated on the device, 1.25e7 x 250 bp per GPU")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's count)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per read (0=auto, 8/16/32/64)")
     ap.add_argument("--table", default="auto", choices=["auto", "direct", "direct8", "hash"])
@@ -56,13 +58,9 @@ def unpack_to_ascii(alphabet, packed_np, length):
     return out.reshape(-1), off
 
 
-def count_entries_torch(torch, sdb, packed, length, chunk=1 << 20):
-    """Exact H = sum over reads and k-mer positions of the matched row length, with plain torch ops
-    (independent of the engine): dense row-length table gather over every k-mer code."""
-    from rappas_amd import synth
-    dev = packed.device
-    k, bits, sigma = sdb.k, sdb.bits, sdb.alphabet
-    Q = length - k + 1
+def row_length_table(sdb):
+    """int32[sigma^k]: row length per dense k-mer index (0 = absent) of a host-side SynthDB."""
+    k, sigma = sdb.k, sdb.alphabet
     lens = (sdb.row_offsets[1:] - sdb.row_offsets[:-1]).astype(np.int64)
     if sigma == 4:
         dense = sdb.key_codes.astype(np.int64)
@@ -72,6 +70,14 @@ def count_entries_torch(torch, sdb, packed, length, chunk=1 << 20):
             dense += ((sdb.key_codes >> np.uint64(5 * i)) & np.uint64(31)).astype(np.int64) * (20 ** i)
     table = np.zeros(sigma ** k, dtype=np.int32)
     table[dense] = lens
+    return table
+
+
+def count_entries_torch(torch, table, sigma, k, bits, packed, length, chunk=1 << 20):
+    """Exact H = sum over reads and k-mer positions of the matched row length, with plain torch ops
+    (independent of the engine): dense row-length table gather over every k-mer code."""
+    dev = packed.device
+    Q = length - k + 1
     table_t = torch.from_numpy(table).to(dev)
     n, wpr = packed.shape
     total = 0
@@ -97,13 +103,48 @@ def count_entries_torch(torch, sdb, packed, length, chunk=1 << 20):
     return total, hits
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one fresh process per GPU).
+
+    Runs before torch is imported or any HIP call is made in this process; the parent never touches the GPU, it only
+    waits, forwards rank 0's JSON line and fails if any rank failed.  Children get RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT exactly as `torch.distributed.run` would set them."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    return 0
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself; torch.distributed.run must use --nproc-per-node N)")
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("RK_BENCH_ECHO_RANK"):  # tests: proof that N separate rank processes were started
+        print(f"bench rank {rank}/{world} pid {os.getpid()}", file=sys.stderr, flush=True)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the placement engine has no CPU fallback")
@@ -117,22 +158,49 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     n_gpus = world
 
     import rappas_amd as ra
     from rappas_amd import synth
 
-    alphabet, k, leaves, n_keys, n_entries, rlen, n_reads_cfg = synth.CONFIGS[a.config]
-    n_reads = a.reads or n_reads_cfg
-    sdb = synth.make_config_db(a.config, seed=42, scale=a.db_scale)
     mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": ra.RK_TABLE_HASH}[a.table]
-    db = ra.PhyloKmerDB.from_synth(sdb, device=local_rank, table_mode=mode)
+    spec = None  # set when the DB exists only in HBM (generated on the device from the seed)
+    if a.config in synth.SPEC_CONFIGS:
+        alphabet, k, leaves, _, _, rlen, n_reads_cfg = synth.SPEC_CONFIGS[a.config]
+        spec = synth.make_spec(a.config, seed=42)
+        if a.db_scale != 1.0:
+            spec.mean_row_len = max(1.0, spec.mean_row_len * a.db_scale)
+        t_db = time.perf_counter()
+        db = ra.PhyloKmerDB.synthetic(spec, device=local_rank, table_mode=mode)
+        t_db = time.perf_counter() - t_db
+        n_branches, bits = spec.n_branches, spec.bits
+        lens_table = spec.row_length_table()
+
+        def oracle_db_for(seq, off):  # the rows these reads touch, regenerated on the host by the generator's numpy twin
+            return O.OracleDB.from_synth(spec.subset_db(synth.codes_of_reads(alphabet, k, seq, off)))
+        db_desc = (f"{db.info.n_keys} keys / {db.info.n_entries} entries ({db.info.rows_bytes / 1e9:.1f} GB image) generated on the "
+                   f"device from seed 42 in {t_db:.1f} s")
+    else:
+        cfg_name = "C2" if a.config == "C3" else a.config
+        alphabet, k, leaves, n_keys, n_entries, rlen, n_reads_cfg = synth.CONFIGS[cfg_name]
+        if a.config == "C3":
+            n_reads_cfg = 125_000_000  # 1e9 reads over 8 GPUs
+        sdb = synth.make_config_db(cfg_name, seed=42, scale=a.db_scale)
+        db = ra.PhyloKmerDB.from_synth(sdb, device=local_rank, table_mode=mode)
+        n_branches, bits = sdb.n_branches, sdb.bits
+        lens_table = row_length_table(sdb)
+
+        def oracle_db_for(seq, off):
+            return O.OracleDB.from_synth(sdb)
+        db_desc = f"{sdb.n_keys} keys / {sdb.n_entries} entries (seed 42)"
+    n_reads = a.reads or n_reads_cfg
     if a.lanes:
         db.set_lanes_per_read(a.lanes)
     pp = ra.PlacementProcess(db)
     K = 7
-    bits = sdb.bits
     wpr = db.packed_words(rlen)
+    from oracle import oracle as O  # checker + cpu_baseline leg only; never inside the timed region
 
     # synthetic reads, uniform i.i.d. symbols, generated on the device straight into the packed layout
     gen = torch.Generator(device=dev)
@@ -165,13 +233,12 @@ def main():
     # ---- correctness gate on a sample before any timing (oracle = checker only) ----
     verified = None
     if a.verify and rank == 0:
-        from oracle import oracle as O
         from tests.util import compare_with_oracle
-        nv = min(a.verify, n_reads)
+        nv = min(a.verify, n_reads, 48 if spec is not None else a.verify)
         step()
         torch.cuda.synchronize()
         seq, off = unpack_to_ascii(alphabet, packed[:nv].cpu().numpy().view(np.uint32), rlen)
-        odb = O.OracleDB.from_synth(sdb)
+        odb = oracle_db_for(seq, off)
         ref = odb.place(seq, off, keep_at_most=K)
         got = ra.Placements(out["n_rows"][:nv].cpu().numpy(), out["branch"][:nv].cpu().numpy().view(np.uint16),
                             out["score"][:nv].cpu().numpy(), out["lwr"][:nv].cpu().numpy(),
@@ -181,7 +248,7 @@ def main():
 
     # ---- algorithmic bytes: B = ceil(R*b/8) + Q*8 + H*6 + (2 + K*14)   ----
     Q = rlen - k + 1
-    H_total, hit_kmers = count_entries_torch(torch, sdb, packed, rlen)
+    H_total, hit_kmers = count_entries_torch(torch, lens_table, alphabet, k, bits, packed, rlen)
     H_mean = H_total / n_reads
     B = math.ceil(rlen * bits / 8) + Q * 8 + H_mean * 6 + (2 + K * 14)
 
@@ -222,13 +289,17 @@ def main():
                     traffic = pj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        sym = "bp DNA" if alphabet == 4 else "aa"
+        metric = {"C2": "reads placed/sec (whole node), 150 bp DNA vs 10^7-kmer DB",
+                  "C3": "reads placed/sec (whole node), 150 bp DNA vs 10^7-kmer DB"}.get(
+                      a.config, f"reads placed/sec (whole node), {rlen} {sym} reads, config {a.config}")
         line = {
-            "metric": "reads placed/sec (whole node), 150 bp DNA vs 10^7-kmer DB",
+            "metric": metric,
             "value": value, "unit": "reads/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.config}: {'DNA' if alphabet == 4 else 'AA'} k={k}, {sdb.n_branches} branches, "
-                                   f"{sdb.n_keys} keys / {sdb.n_entries} entries phylo-kmer DB (seed 42) replicated per GPU, "
+            "config": {"workload": f"{a.config}: {'DNA' if alphabet == 4 else 'AA'} k={k}, {n_branches} branches, "
+                                   f"phylo-kmer DB of {db_desc}, replicated per GPU; "
                                    f"{n_reads} x {rlen} symbol reads per GPU per step (uniform, seed 1+rank), keep_at_most=7",
                        "table": {ra.RK_TABLE_DIRECT: "direct (compact 1.33 B/k-mer blocks)", ra.RK_TABLE_DIRECT8: "direct8", ra.RK_TABLE_HASH: "hash"}[db.info.table_mode],
                        "kernel": db.kernel_name(), "reads_per_gpu": n_reads, "sharding": f"reads x{n_gpus}, DB replicated"},
@@ -238,22 +309,23 @@ def main():
             "verified_vs_oracle": verified,
         }
         if not a.no_cpu_baseline and n_gpus == 1:
-            from oracle import oracle as O
             # bounded sample: about 10 s of single-thread work (the oracle does ~1.6e7 row entries per second)
-            ns = min(a.cpu_sample, n_reads, max(2000, int(1.6e8 / max(1.0, H_mean))))
+            ns = min(a.cpu_sample, n_reads, max(64 if spec is not None else 2000, int(1.6e8 / max(1.0, H_mean))))
             seq, off = unpack_to_ascii(alphabet, packed[:ns].cpu().numpy().view(np.uint32), rlen)
-            odb = O.OracleDB.from_synth(sdb)
-            odb.place(seq[:int(off[min(ns, 2000)])], off[:min(ns, 2000) + 1], keep_at_most=K)  # warm caches
+            odb = oracle_db_for(seq, off)
+            nw = min(ns, 2000)
+            odb.place(seq[:int(off[nw])], off[:nw + 1], keep_at_most=K)  # warm caches
             c0 = time.perf_counter()
             odb.place(seq, off, keep_at_most=K)
             cdt = time.perf_counter() - c0
             line["cpu_baseline"] = {"value": ns / cdt, "unit": "reads/s", "cores": 1, "kind": "port",
-                                    "sample": f"first {ns} reads of rank 0's batch, same DB, oracle/rappas_oracle.c "
-                                              f"(single thread, like the reference's placement loop), {cdt:.1f} s"}
+                                    "sample": f"first {ns} reads of rank 0's batch, "
+                                              + ("the DB rows those reads touch regenerated on the host, " if spec is not None else "same DB, ")
+                                              + f"oracle/rappas_oracle.c (single thread, like the reference's placement loop), {cdt:.1f} s"}
             # the same oracle on every host core (reads split into contiguous chunks, one thread each; ctypes drops the GIL)
             from concurrent.futures import ThreadPoolExecutor
             ncore = max(1, min(os.cpu_count() or 1, 64))
-            nall = min(n_reads, ns * min(ncore, 8))
+            nall = ns if spec is not None else min(n_reads, ns * min(ncore, 8))  # (a generated DB exists on the host only for the sample)
             seq_a, off_a = (seq, off) if nall == ns else unpack_to_ascii(alphabet, packed[:nall].cpu().numpy().view(np.uint32), rlen)
             bounds = [nall * i // ncore for i in range(ncore + 1)]
 

@@ -129,6 +129,30 @@ int rk_db_validate(const rk_db_desc *desc, rk_db_info *info);
 void rk_db_destroy(rk_db *db);
 int rk_db_get_info(const rk_db *db, rk_db_info *info);
 
+/* One row read back out of the HBM image through the same table lookup and entry decode the placement kernels use:
+ * the engine's counterpart of CustomHash_v4_FastUtil81.getPairsOfTopPosition2 (src/core/hash/CustomHash_v4_FastUtil81.java:146-153;
+ * null there <=> *len == 0 here).  Entries come back in the image's order (large-tree images: ascending branch id).  At most
+ * `cap` entries are written; *len is the row's full length.  For checkers and tools, not for the hot path (one launch per call). */
+int rk_db_fetch_row(rk_db *db, uint64_t code, uint32_t cap, uint32_t *len, uint16_t *branch_ids, float *scores);
+
+/* The seeded synthetic database of the measurement plan (keys = a random subset of the code space,
+ * row length 1 + geometric, branch ids a contiguous window, scores v = T*u), generated ON THE DEVICE straight into the HBM
+ * image -- the only way a C5-class (~200 GB) database can exist, since no host holds its CSR form.  Every value is a pure
+ * function of (seed, dense k-mer index, entry index) in integer arithmetic plus one float32 multiply (definition at the top of
+ * rappas_amd/csrc/rk_synth_impl.h), so a checker regenerates any row on the host (rappas_amd/synth.py: synth_rows) and
+ * rk_db_fetch_row reads it back.  The reference has no counterpart (its databases come out of `-p b`); this is bench / test
+ * input, built by the same library because only the library knows the image format. */
+typedef struct rk_synth_desc {
+    uint32_t alphabet, convert_uo, k, n_branches;
+    float thr_log10, thr;
+    uint64_t seed;
+    double key_fraction;  /* probability that a code of the k-mer space carries a row, in (0, 1] */
+    double mean_row_len;  /* rows are 1 + geometric with this mean, capped at n_branches - 1 */
+    int32_t device;
+    uint32_t table_mode;  /* RK_TABLE_* */
+} rk_synth_desc;
+int rk_db_create_synth(const rk_synth_desc *desc, rk_db **out);
+
 /* Host-buffer entry point: ASCII reads (concatenated, seq_off[n_reads+1]) -> results in host memory.
  * Internally: H2D, device-side pack, placement kernel(s), D2H; chunked to bound device memory. */
 int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,

@@ -43,6 +43,14 @@ class rk_result(C.Structure):
     _fields_ = [("n_rows", C.c_void_p), ("branch", C.c_void_p), ("score", C.c_void_p), ("lwr", C.c_void_p), ("flags", C.c_void_p)]
 
 
+class rk_synth_desc(C.Structure):
+    _fields_ = [
+        ("alphabet", C.c_uint32), ("convert_uo", C.c_uint32), ("k", C.c_uint32), ("n_branches", C.c_uint32),
+        ("thr_log10", C.c_float), ("thr", C.c_float), ("seed", C.c_uint64), ("key_fraction", C.c_double),
+        ("mean_row_len", C.c_double), ("device", C.c_int32), ("table_mode", C.c_uint32),
+    ]
+
+
 class rk_build_desc(C.Structure):
     _fields_ = [
         ("alphabet", C.c_uint32), ("k", C.c_uint32), ("n_nodes", C.c_uint32), ("n_sites", C.c_uint32), ("n_states", C.c_uint32),
@@ -69,6 +77,8 @@ EXPORTS = {
     "rk_db_validate": (C.c_int, [C.POINTER(rk_db_desc), C.POINTER(rk_db_info)]),
     "rk_db_destroy": (None, [C.c_void_p]),
     "rk_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(rk_db_info)]),
+    "rk_db_fetch_row": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
+    "rk_db_create_synth": (C.c_int, [C.POINTER(rk_synth_desc), C.POINTER(C.c_void_p)]),
     "rk_place_batch": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.POINTER(rk_result), C.POINTER(rk_counters)]),
     "rk_place_batch_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rk_params), C.c_uint64, C.c_void_p,

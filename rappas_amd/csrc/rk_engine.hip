@@ -241,6 +241,126 @@ extern "C" void rk_db_destroy(rk_db *db) {
     delete db;
 }
 
+// scalars every database carries, whatever built its image
+struct DbMeta {
+    uint32_t alphabet, convert_uo, k, n_branches;
+    float thr_log10, thr;
+};
+
+// device selection, properties, spare stream and the alphabet tables; the caller restores the current device
+static int open_db(const DbMeta &m, int device, rk_db **out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RK_ERR_NO_DEVICE, "rk_db_create: no HIP device available (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(RK_ERR_INVALID, "rk_db_create: device %d out of range (0..%d)", device, ndev - 1);
+    rk_db *db = new (std::nothrow) rk_db();
+    if (!db) return fail(RK_ERR_NOMEM, "rk_db_create: host OOM");
+    db->info.device = device;
+#define OPEN_TRY(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            int c_ = fail(e_ == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            rk_db_destroy(db);                                                                    \
+            return c_;                                                                            \
+        }                                                                                         \
+    } while (0)
+    OPEN_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OPEN_TRY(hipGetDeviceProperties(&prop, device));
+    db->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    db->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
+    OPEN_TRY(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
+    OPEN_TRY(hipMalloc((void **)&db->d_alpha, 256 + 320 + 16));
+    Alphabet A;
+    build_alphabet(m.alphabet, m.convert_uo != 0, A);
+    OPEN_TRY(hipMemcpy(db->d_alpha, A.table, 256, hipMemcpyHostToDevice));
+    OPEN_TRY(hipMemcpy(db->d_alpha + 256, A.alts, 320, hipMemcpyHostToDevice));
+    OPEN_TRY(hipMemcpy(db->d_alpha + 576, A.alt_count, 16, hipMemcpyHostToDevice));
+#undef OPEN_TRY
+    *out = db;
+    return RK_OK;
+}
+
+// info + device view once d_table / d_rows hold the image
+static void finish_db(rk_db *db, const DbMeta &m, uint32_t mode, bool indexed, bool mono, uint64_t n_keys, uint64_t n_entries,
+                      uint64_t slots, uint64_t hash_mask, uint64_t table_bytes, uint64_t blob_bytes, uint32_t max_len) {
+    const uint32_t bits = m.alphabet == RK_ALPHABET_DNA ? 2 : 5;
+    db->convert_uo = m.convert_uo;
+    db->indexed = indexed;
+    db->info.alphabet = m.alphabet; db->info.k = m.k; db->info.n_branches = m.n_branches;
+    db->info.table_mode = mode; db->info.thr_log10 = m.thr_log10; db->info.thr = m.thr;
+    db->info.n_keys = n_keys; db->info.n_entries = n_entries; db->info.table_slots = slots;
+    db->info.table_bytes = table_bytes; db->info.rows_bytes = blob_bytes; db->info.bits_per_symbol = bits;
+    db->info.max_row_len = max_len;
+    db->view.direct = mode == RK_TABLE_DIRECT8 ? (const u64 *)db->d_table : nullptr;
+    db->view.compact = mode == RK_TABLE_DIRECT ? (const uint4 *)db->d_table : nullptr;
+    db->view.slots = mode == RK_TABLE_HASH ? (const uint4 *)db->d_table : nullptr;
+    db->view.hash_mask = hash_mask;
+    db->view.rows = (const unsigned char *)db->d_rows;
+    db->view.rows_bytes = db->info.rows_bytes;
+    db->view.k = m.k; db->view.bits = bits; db->view.n_branches = m.n_branches; db->view.alphabet = m.alphabet;
+    db->view.T = m.thr_log10; db->view.P = m.thr; db->view.convert_uo = m.convert_uo;
+    db->view.soa = indexed ? 1u : 0u;
+    db->view.mono = mono ? 1u : 0u;
+}
+
+static int check_launchable(const rk_db *db);
+
+// ---- k-mer -> row descriptor table, keys given in ascending dense-index order through the accessors ----
+// DIRECT  : compact blocks, 16 bytes per 12 consecutive k-mers {u32 first row unit, 12 x u8 units per row}: 1.33 bytes
+//           per k-mer (1.4 MiB at k=10), small enough to live in the XCD L2s, one dwordx4 gather per probe; a row's
+//           offset is the block base plus a byte prefix sum.  Needs rows of <= 255 units (4080 entries) and a blob
+//           of < 2^32 units (512 GiB); otherwise DIRECT falls back to DIRECT8.
+// DIRECT8 : one 8-byte descriptor per k-mer.
+// HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
+template <class FDense, class FDesc, class FCode>
+static int build_table(uint32_t &mode, uint64_t space, uint64_t n_keys, bool indexed, uint64_t max_units, uint64_t blob_units,
+                       FDense dense_of, FDesc desc_of, FCode code_of, std::vector<uint64_t> &table, uint64_t &slots, uint64_t &hash_mask) {
+    if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32) || indexed)) mode = RK_TABLE_DIRECT8;
+    slots = 0; hash_mask = 0;
+    try {
+        if (mode == RK_TABLE_DIRECT) {
+            slots = space;
+            const uint64_t n_blocks = (space + COMPACT_KMERS - 1) / COMPACT_KMERS;
+            table.assign(n_blocks * 2, 0);
+            unsigned char *tb = (unsigned char *)table.data();
+            uint64_t next_unit = 1, ki = 0;
+            for (uint64_t blk = 0; blk < n_blocks; blk++) {
+                const uint32_t base32 = (uint32_t)next_unit;
+                memcpy(tb + blk * 16, &base32, 4);
+                while (ki < n_keys && dense_of(ki) / COMPACT_KMERS == blk) {
+                    const uint64_t units = ((uint32_t)desc_of(ki) & DESC_LEN_MASK) / ROW_UNIT;
+                    tb[blk * 16 + 4 + (dense_of(ki) % COMPACT_KMERS)] = (unsigned char)units;
+                    next_unit += units;
+                    ki++;
+                }
+            }
+        } else if (mode == RK_TABLE_DIRECT8) {
+            slots = space;
+            table.assign(slots, 0);
+            for (uint64_t i = 0; i < n_keys; i++) table[dense_of(i)] = desc_of(i);
+        } else {
+            slots = 16;
+            while (slots < 2 * n_keys) slots <<= 1;
+            hash_mask = slots - 1;
+            table.assign(slots * 2, 0);
+            for (uint64_t i = 0; i < n_keys; i++) {
+                const uint64_t code = code_of(i);
+                uint64_t h = host_mix64(code) & hash_mask;
+                while (table[2 * h]) h = (h + 1) & hash_mask;
+                table[2 * h] = code + 1;
+                table[2 * h + 1] = desc_of(i);
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(RK_ERR_NOMEM, "rk_db_create: host OOM building the k-mer table");
+    }
+    return RK_OK;
+}
+
 // Validation + host-side construction of the HBM image (no HIP call in here: rk_db_validate runs it without a device).
 struct DbImage {
     uint32_t mode = 0, bits = 0, max_len = 0;
@@ -433,52 +553,11 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     }
 
     // ---- table ----
-    // DIRECT  : compact blocks, 16 bytes per 12 consecutive k-mers {u32 first row unit, 12 x u8 units per row}: 1.33 bytes
-    //           per k-mer (1.4 MiB at k=10), small enough to live in the XCD L2s, one dwordx4 gather per probe; a row's
-    //           offset is the block base plus a byte prefix sum.  Needs rows of <= 255 units (4080 entries) and a blob
-    //           of < 2^32 units (512 GiB); otherwise DIRECT falls back to DIRECT8.
-    // DIRECT8 : one 8-byte descriptor per k-mer.
-    // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
-    if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32) || indexed)) mode = RK_TABLE_DIRECT8;
-    std::vector<uint64_t> &table = img.table;
-    uint64_t &slots = img.slots, &hash_mask = img.hash_mask;
-    slots = 0; hash_mask = 0;
-    try {
-        if (mode == RK_TABLE_DIRECT) {
-            slots = space;
-            const uint64_t n_blocks = (space + COMPACT_KMERS - 1) / COMPACT_KMERS;
-            table.assign(n_blocks * 2, 0);
-            unsigned char *tb = (unsigned char *)table.data();
-            uint64_t next_unit = 1, ki = 0;
-            for (uint64_t blk = 0; blk < n_blocks; blk++) {
-                const uint32_t base32 = (uint32_t)next_unit;
-                memcpy(tb + blk * 16, &base32, 4);
-                while (ki < n_keys && order[ki].first / COMPACT_KMERS == blk) {
-                    const uint64_t units = ((uint32_t)desc[order[ki].second] & DESC_LEN_MASK) / ROW_UNIT;
-                    tb[blk * 16 + 4 + (order[ki].first % COMPACT_KMERS)] = (unsigned char)units;
-                    next_unit += units;
-                    ki++;
-                }
-            }
-        } else if (mode == RK_TABLE_DIRECT8) {
-            slots = space;
-            table.assign(slots, 0);
-            for (uint64_t i = 0; i < n_keys; i++) table[order[i].first] = desc[order[i].second];
-        } else {
-            slots = 16;
-            while (slots < 2 * n_keys) slots <<= 1;
-            hash_mask = slots - 1;
-            table.assign(slots * 2, 0);
-            for (uint64_t r = 0; r < n_keys; r++) {
-                const uint64_t code = d->key_codes[r];
-                uint64_t h = host_mix64(code) & hash_mask;
-                while (table[2 * h]) h = (h + 1) & hash_mask;
-                table[2 * h] = code + 1;
-                table[2 * h + 1] = desc[r];
-            }
-        }
-    } catch (const std::bad_alloc &) {
-        return fail(RK_ERR_NOMEM, "rk_db_create: host OOM building the k-mer table");
+    {
+        int rc = build_table(img.mode, space, n_keys, indexed, max_units, blob_units,
+                             [&](uint64_t i) { return order[i].first; }, [&](uint64_t i) { return desc[order[i].second]; },
+                             [&](uint64_t i) { return d->key_codes[order[i].second]; }, img.table, img.slots, img.hash_mask);
+        if (rc) return rc;
     }
 
     img.blob_bytes = blob_bytes;
@@ -508,24 +587,20 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
         int rc = build_image(d, img);  // argument errors are reported before the device is looked at
         if (rc) return rc;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(RK_ERR_NO_DEVICE, "rk_db_create: no HIP device available (this engine has no CPU fallback)");
-    if (d->device < 0 || d->device >= ndev)
-        return fail(RK_ERR_INVALID, "rk_db_create: device %d out of range (0..%d)", d->device, ndev - 1);
-    const uint32_t mode = img.mode, bits = img.bits, max_len = img.max_len;
+    const uint32_t mode = img.mode, max_len = img.max_len;
     const bool indexed = img.indexed;
     const uint64_t n_keys = img.n_keys, n_entries = img.n_entries, blob_bytes = img.blob_bytes, slots = img.slots, hash_mask = img.hash_mask;
     std::vector<Entry> &blob = img.blob;
     std::vector<uint64_t> &table = img.table;
 
     // ---- upload ----
-    rk_db *db = new (std::nothrow) rk_db();
-    if (!db) return fail(RK_ERR_NOMEM, "rk_db_create: host OOM");
-    db->info.device = d->device;
+    rk_db *db = nullptr;
     int prev = 0;
     (void)hipGetDevice(&prev);
     struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+    DbMeta meta{d->alphabet, d->convert_uo, d->k, d->n_branches, d->thr_log10, d->thr};
+    int rc = open_db(meta, d->device, &db);
+    if (rc) return rc;
 #define DB_TRY(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -535,42 +610,15 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
             return c_;                                                                            \
         }                                                                                         \
     } while (0)
-    DB_TRY(hipSetDevice(d->device));
-    hipDeviceProp_t prop;
-    DB_TRY(hipGetDeviceProperties(&prop, d->device));
-    db->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    db->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
-    DB_TRY(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
     const size_t table_bytes = table.size() * sizeof(uint64_t);
     DB_TRY(hipMalloc(&db->d_table, table_bytes ? table_bytes : 8));
     DB_TRY(hipMalloc(&db->d_rows, blob_bytes));
-    DB_TRY(hipMalloc((void **)&db->d_alpha, 256 + 320 + 16));
     if (table_bytes) DB_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
     DB_TRY(hipMemcpy(db->d_rows, blob.data(), blob_bytes, hipMemcpyHostToDevice));
-    Alphabet A;
-    build_alphabet(d->alphabet, d->convert_uo != 0, A);
-    DB_TRY(hipMemcpy(db->d_alpha, A.table, 256, hipMemcpyHostToDevice));
-    DB_TRY(hipMemcpy(db->d_alpha + 256, A.alts, 320, hipMemcpyHostToDevice));
-    DB_TRY(hipMemcpy(db->d_alpha + 576, A.alt_count, 16, hipMemcpyHostToDevice));
 #undef DB_TRY
-
-    db->convert_uo = d->convert_uo;
-    db->indexed = indexed;
-    db->info.alphabet = d->alphabet; db->info.k = d->k; db->info.n_branches = d->n_branches;
-    db->info.table_mode = mode; db->info.thr_log10 = d->thr_log10; db->info.thr = d->thr;
-    db->info.n_keys = n_keys; db->info.n_entries = n_entries; db->info.table_slots = slots;
-    db->info.table_bytes = table_bytes; db->info.rows_bytes = blob_bytes; db->info.bits_per_symbol = bits;
-    db->info.max_row_len = max_len;
-    db->view.direct = mode == RK_TABLE_DIRECT8 ? (const u64 *)db->d_table : nullptr;
-    db->view.compact = mode == RK_TABLE_DIRECT ? (const uint4 *)db->d_table : nullptr;
-    db->view.slots = mode == RK_TABLE_HASH ? (const uint4 *)db->d_table : nullptr;
-    db->view.hash_mask = hash_mask;
-    db->view.rows = (const unsigned char *)db->d_rows;
-    db->view.rows_bytes = db->info.rows_bytes;
-    db->view.k = d->k; db->view.bits = bits; db->view.n_branches = d->n_branches; db->view.alphabet = d->alphabet;
-    db->view.T = d->thr_log10; db->view.P = d->thr; db->view.convert_uo = d->convert_uo;
-    db->view.soa = indexed ? 1u : 0u;
-    db->view.mono = img.mono ? 1u : 0u;
+    finish_db(db, meta, mode, indexed, img.mono, n_keys, n_entries, slots, hash_mask, table_bytes, blob_bytes, max_len);
+    rc = check_launchable(db);  // a tree whose score vector no kernel geometry can hold is refused here, not at the first batch
+    if (rc) { rk_db_destroy(db); return rc; }
     *out = db;
     return RK_OK;
 }
@@ -777,6 +825,15 @@ static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
         return RK_OK;
     }
     return fail(RK_ERR_UNSUPPORTED, "n_branches=%u: the score vector does not fit one CU's LDS (%zu B)", nb, db->lds_per_cu);
+}
+
+static int check_launchable(const rk_db *db) {
+    if (db->indexed) {
+        WgGeometry wg;
+        return choose_wg_geometry(db, wg);
+    }
+    Geometry g;
+    return choose_geometry(db, 7, g);
 }
 
 template <int BITS, int TM>
@@ -1085,6 +1142,8 @@ done:
     if (counters) *counters = ct;
     return RK_OK;
 }
+
+#include "rk_synth_impl.h"
 
 #ifdef RK_STAMPS
 // diagnostic builds only (scripts/stamps.py)

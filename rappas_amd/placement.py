@@ -72,6 +72,31 @@ class PhyloKmerDB:
         self.info = info
 
     @classmethod
+    def synthetic(cls, spec, device=0, table_mode=RK_TABLE_AUTO, convert_uo=False):
+        """The seeded synthetic database of SURVEY 8(d) generated on the device straight into the HBM image
+        (rk_db_create_synth); `spec` is a rappas_amd.synth.SynthSpec, whose numpy twin regenerates any row on the host."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        d = _lib.rk_synth_desc(spec.alphabet, int(bool(convert_uo)), spec.k, spec.n_branches, float(spec.thr_log10), float(spec.thr),
+                               int(spec.seed) & 0xFFFFFFFFFFFFFFFF, float(spec.key_fraction), float(spec.mean_row_len), device, table_mode)
+        _lib.check(self._lib.rk_db_create_synth(C.byref(d), C.byref(self._h)))
+        info = rk_db_info()
+        _lib.check(self._lib.rk_db_get_info(self._h, C.byref(info)))
+        self.info = info
+        return self
+
+    def fetch_row(self, code):
+        """(branch_ids u16[len], scores f32[len]) of one k-mer code as stored in the HBM image; empty arrays if absent
+        (CustomHash_v4_FastUtil81.getPairsOfTopPosition2, src/core/hash/CustomHash_v4_FastUtil81.java:146-153)."""
+        n = C.c_uint32(0)
+        cap = int(self.info.max_row_len)
+        br = np.zeros(max(cap, 1), np.uint16)
+        sc = np.zeros(max(cap, 1), np.float32)
+        _lib.check(self._lib.rk_db_fetch_row(self.handle, int(code), cap, C.byref(n), _ptr(br), _ptr(sc)))
+        return br[:n.value].copy(), sc[:n.value].copy()
+
+    @classmethod
     def from_synth(cls, db, **kw):
         return cls(db.alphabet, db.k, db.n_branches, db.thr_log10, db.thr, db.key_codes, db.row_offsets,
                    db.branch_ids, db.scores, **kw)

@@ -101,6 +101,152 @@ def make_db(alphabet, k, n_branches, n_keys, n_entries, seed=42, omega=1.5, sort
     return SynthDB(alphabet, k, n_branches, thr, thr_log10, key_codes, row_offsets, branch_ids, scores, seed)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Counter-based generator: the host twin of rk_db_create_synth (rappas_amd/csrc/rk_synth_impl.h states the definition).
+# The engine fills the HBM image from (seed, dense k-mer index, entry index) on the device; the functions below regenerate
+# the same rows with numpy so that a checker can hand the rows a read touches to the oracle without the database ever
+# existing on the host (C5: ~200 GB).
+# ----------------------------------------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix(x):
+    x = np.asarray(x, dtype=np.uint64).copy()
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+@dataclass
+class SynthSpec:
+    alphabet: int
+    k: int
+    n_branches: int
+    thr: np.float32
+    thr_log10: np.float32
+    seed: int
+    key_fraction: float
+    mean_row_len: float
+
+    @property
+    def bits(self):
+        return 2 if self.alphabet == 4 else 5
+
+    @property
+    def space(self):
+        return self.alphabet ** self.k
+
+    @property
+    def max_len(self):
+        return max(1, self.n_branches - 1)
+
+    def surv(self):
+        """surv[0] = 2^32, surv[j] = (surv[j-1] * q) >> 32 with q = floor((1 - 1/mean) * 2^32): P(len > j) in 32-bit fixed point."""
+        if getattr(self, "_surv", None) is None:
+            q = int((1.0 - 1.0 / float(self.mean_row_len)) * 4294967296.0)
+            out = [1 << 32]
+            while len(out) < self.max_len and out[-1] != 0:
+                out.append((out[-1] * q) >> 32)
+            self._surv = np.array(out, dtype=np.uint64)
+        return self._surv
+
+    def h0(self, dense):
+        with np.errstate(over="ignore"):
+            return _mix(np.uint64(self.seed & 0xFFFFFFFFFFFFFFFF) + (np.asarray(dense, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+
+    def present_and_lens(self, dense):
+        """(present bool[n], len int64[n]) for dense k-mer indices; len is meaningful where present."""
+        h0 = self.h0(dense)
+        thresh = np.uint64(int(float(self.key_fraction) * 4294967296.0))
+        present = (h0 >> np.uint64(32)) < thresh
+        r = _mix(h0 ^ np.uint64(0xA0761D6478BD642F)) >> np.uint64(32)
+        sv = self.surv()
+        # first j in [1, n) with surv[j] <= r  ==  1 + #{j in [1, n): surv[j] > r}; surv is non-increasing
+        tail = sv[1:][::-1]  # ascending
+        cnt = len(tail) - np.searchsorted(tail, r, side="right")
+        lens = np.minimum(1 + cnt, self.max_len).astype(np.int64)
+        return present, lens
+
+    def rows(self, dense):
+        """CSR rows (row_offsets u64[n+1], branch_ids u16, scores f32) of the given PRESENT dense indices, in the given order."""
+        dense = np.asarray(dense, dtype=np.uint64)
+        h0 = self.h0(dense)
+        _, lens = self.present_and_lens(dense)
+        n = len(dense)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        total = int(off[-1])
+        if self.n_branches == 1:
+            b0 = np.zeros(n, dtype=np.int64)
+        else:
+            hi = np.maximum(1, self.n_branches - lens).astype(np.uint64)
+            b0 = 1 + (((_mix(h0 ^ np.uint64(0xE7037ED1A0B428DB)) >> np.uint64(32)) * hi) >> np.uint64(32)).astype(np.int64)
+        within = np.arange(total, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
+        branch = (np.repeat(b0, lens) + within).astype(np.uint16)
+        with np.errstate(over="ignore"):
+            hs = _mix(np.repeat(h0, lens) + (within.astype(np.uint64) + np.uint64(1)) * np.uint64(0xD6E8FEB86659FD93))
+        u = (hs >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+        scores = (np.float32(self.thr_log10) * u).astype(np.float32)
+        return off, branch, scores
+
+    def subset_db(self, dense):
+        """SynthDB holding exactly the rows of the given dense indices that are present (for the oracle / rk_db_create)."""
+        dense = np.unique(np.asarray(dense, dtype=np.uint64))
+        present, _ = self.present_and_lens(dense)
+        dense = dense[present]
+        off, branch, scores = self.rows(dense)
+        return SynthDB(self.alphabet, self.k, self.n_branches, self.thr, self.thr_log10,
+                       dense_to_code(self.alphabet, self.k, dense), off, branch, scores, self.seed)
+
+    def row_length_table(self):
+        """int32[sigma^k]: row length per dense index, 0 where absent (for exact entry counts H)."""
+        out = np.zeros(self.space, dtype=np.int32)
+        step = 1 << 22
+        for a in range(0, self.space, step):
+            d = np.arange(a, min(self.space, a + step), dtype=np.uint64)
+            p, ln = self.present_and_lens(d)
+            out[a:a + len(d)] = np.where(p, ln, 0)
+        return out
+
+
+# name: (alphabet, k, leaves, key_fraction, mean_row_len, read_len, reads per GPU)
+SPEC_CONFIGS = {
+    # BASELINE C5: 10k-leaf DNA tree, k=12, ~3.3e10 entries (6 B each ~ 198 GB) -- 12 582 912 keys x rows of ~2 622
+    "C5": (4, 12, 10_000, 0.75, 3.3e10 / 12_582_912, 250, 12_500_000),
+    # the same generator at sizes tests can hold
+    "C5tiny": (4, 8, 10_000, 0.75, 400.0, 250, 2_000),
+}
+
+
+def make_spec(name, seed=42, omega=1.5, mean_row_len=None, key_fraction=None):
+    alphabet, k, leaves, kf, mean, _, _ = SPEC_CONFIGS[name]
+    thr, thr_log10 = thresholds(omega, alphabet, k)
+    return SynthSpec(alphabet, k, 2 * leaves - 1, thr, thr_log10, seed, key_fraction or kf, mean_row_len or mean)
+
+
+def codes_of_reads(alphabet, k, seq, off):
+    """dense k-mer indices of every window of every (unambiguous, equal-length or ragged) ASCII read -> u64 array (flat)."""
+    letters = DNA_LETTERS if alphabet == 4 else AA_LETTERS
+    table = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(letters):
+        table[ch] = i
+        table[ch + 32] = i
+    out = []
+    for r in range(len(off) - 1):
+        st = table[seq[int(off[r]):int(off[r + 1])]].astype(np.uint64)
+        if len(st) < k or (st == 255).any():
+            continue
+        Q = len(st) - k + 1
+        idx = np.zeros(Q, dtype=np.uint64)
+        for i in range(k):
+            idx += st[i:i + Q] * np.uint64(alphabet ** i)
+        out.append(idx)
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint64)
+
+
 def make_config_db(name, seed=42, scale=1.0):
     alphabet, k, leaves, n_keys, n_entries, _, _ = CONFIGS[name]
     return make_db(alphabet, k, 2 * leaves - 1, int(n_keys * scale) if scale != 1.0 else n_keys,

@@ -143,3 +143,25 @@ def test_db_validate_rejects_bad_input():
     codes = aa.key_codes.copy(); codes[0] = 21            # digit 21 >= 20
     with pytest.raises(ra.RkError, match="invalid k-mer code"):
         _validate(aa, key_codes=codes)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py --gpus N either starts N ranks itself or is started as one of N; anything else is an error, not a 1-rank run"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
+def test_bench_gpus_n_launches_n_ranks_and_fails_if_a_rank_fails():
+    """without a GPU every rank exits with the 'needs an MI355X' error: the launcher must report that, not hide it"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["RK_BENCH_ECHO_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "1000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--verify", "0"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and "ranks failed" in p.stderr
+    assert p.stderr.count("bench rank") == 2 and "rank 0/2" in p.stderr and "rank 1/2" in p.stderr

@@ -1,0 +1,50 @@
+"""GPU (-m gpu): bench.py's contract -- `--gpus N` really starts N ranks (one process per GPU), every config named in
+BASELINE.json has a bench leg, and the JSON line carries roofline + cpu_baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks_and_reports_the_whole_job():
+    """two ranks rehearsed on the one GPU of this box (gloo for the barrier / max-over-ranks; RCCL needs one GPU per rank)"""
+    common = ["--reads", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--verify", "300"]
+    one = run_bench("--gpus", "1", *common)
+    two = run_bench("--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", *common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["sharding"].startswith("reads x2")
+    # value = reads of ALL ranks / max-over-ranks time
+    assert abs(two["value"] - 2 * 200000 * 3 / (two["ms_per_step"] * 3 / 1e3)) / two["value"] < 1e-6
+    # both ranks share one GPU here, so the whole-job rate stays near the one-rank rate (it would double on two GPUs)
+    assert 0.4 * one["value"] < two["value"] < 1.6 * one["value"], (one["value"], two["value"])
+    for line in (one, two):
+        assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+        assert line["verified_vs_oracle"]["reads"] == 300
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
+@pytest.mark.parametrize("config,reads", [("C1", "1000"), ("C4", "100000"), ("C3", "2000000")])
+def test_other_configs_have_a_bench_leg(config, reads):
+    line = run_bench("--config", config, "--reads", reads, "--steps", "2", "--warmup", "1", "--cpu-sample", "2000", "--verify", "500")
+    assert line["config"]["workload"].startswith(config + ":")
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["verified_vs_oracle"]["reads"] == 500
