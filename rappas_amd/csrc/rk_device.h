@@ -73,6 +73,7 @@ struct PlaceArgs {
     // geometry
     u32 s_stride;  // u32 words per read score vector in LDS
     u32 list_cap;  // u64 slots of the per-read hit list in LDS
+    u32 n_pass;    // large-tree kernels: branch-range passes per read (1 unless the score vector exceeds one CU's LDS)
 };
 
 __device__ __forceinline__ u64 mix64(u64 x) {

@@ -755,11 +755,20 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
     return RK_OK;
 }
 
+// 16 lanes per read, direct table, 32-bit row offsets, packed record of <= 16 words: the tile-pipelined kernel
+static bool use_pipelined16(const rk_db *db, const Geometry &g, const PlaceArgs &args) {
+    static const bool off = getenv("RK_NO_PIPE") != nullptr;  // developer knob: A/B against place_packed_kernel
+    return !off && g.G == 16 && db->info.table_mode != RK_TABLE_HASH && db->info.rows_bytes < ROWS_FIT32_LIMIT && args.words_per_read <= 16;
+}
+
 template <int G, int BITS, int TM, bool WIDE>
 static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
     constexpr int PU = G <= 16 ? 9 : (G == 32 ? 5 : 3);
     constexpr int U = RK_RING;
     auto kern = place_packed_kernel<G, BITS, TM, WIDE, U, PU>;
+    if constexpr (G == 16 && !WIDE && TM != TM_HASH) {
+        if (use_pipelined16(db, g, args)) kern = place_packed16_kernel<BITS, TM, U, PU>;
+    }
     const uint32_t wpb = db->waves_per_block;
     const size_t lds = g.lds_per_wave * wpb;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -802,29 +811,48 @@ static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, 
 
 // ---- large trees: one workgroup per read ----
 struct WgGeometry {
-    uint32_t nw, s_stride, list_cap, wgs_per_cu;
+    uint32_t nw, s_stride, list_cap, wgs_per_cu, n_pass;
     size_t lds;
 };
 
+// The score vector of one read (4 bytes per branch) is shared by the NW waves of a workgroup.  While it fits, one pass:
+// two workgroups of 8 waves per CU when two vectors fit (C5: 19 999 branches = 80 KB), else one of 16 waves.  Trees beyond one
+// CU's LDS (about 39 000 branches; the reference's limit is the 16-bit id: 65 534) take 2 or 4 branch-range passes per read.
 static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
     const uint32_t nb = db->info.n_branches;
-    g.s_stride = (nb + 4) & ~3u;
-    const size_t s_bytes = (size_t)g.s_stride * 4;
-    const size_t extra = 256;  // per-wave counters
-    // two workgroups of 8 waves per CU when two score vectors fit, else one workgroup of 16 waves
-    for (uint32_t wgs : {2u, 1u}) {
-        const size_t budget = db->lds_per_cu / wgs;
-        const uint32_t nw_try = wgs == 2 ? 8 : 16;
-        if (budget < s_bytes + extra + (size_t)(nw_try * 16 + 16 + 2) * 8) continue;  // level-2 select scratch must fit the list
-        size_t cap = (budget - s_bytes - extra) / 8;
-        if (cap > 512) cap = 512;
-        g.list_cap = (uint32_t)cap & ~1u;
-        g.wgs_per_cu = wgs;
-        g.nw = wgs == 2 ? 8 : 16;
-        g.lds = s_bytes + (size_t)g.list_cap * 8 + extra;
-        return RK_OK;
+    uint32_t min_pass = 1;
+    if (const char *e = getenv("RK_WG_PASSES")) min_pass = (uint32_t)atoi(e);  // developer / test knob: force 2 or 4 passes on a tree that fits in one
+    for (uint32_t P : {1u, 2u, 4u}) {
+        if (P < min_pass) continue;
+        const uint32_t span = 32 / P;
+        uint32_t win = 0;
+        for (uint32_t p = 0; p < P; p++) {
+            const uint32_t lo = (uint32_t)(((uint64_t)p * span * nb) / 32), hi = (uint32_t)(((uint64_t)(p + 1) * span * nb) / 32);
+            win = std::max(win, hi - lo);
+        }
+        const uint32_t s_stride = (win + 4) & ~3u;  // >= win + 1 (word win is the scratch slot), multiple of 4 (b128 scans)
+        const size_t s_bytes = (size_t)s_stride * 4;
+        for (uint32_t wgs : {2u, 1u}) {
+            if (P > 1 && wgs == 2) continue;  // (a tree that needs passes with 8 waves fits whole with 16)
+            const uint32_t nw = wgs == 2 ? 8 : 16;
+            const size_t budget = db->lds_per_cu / wgs;
+            // P == 1: the wave winners of the level-1 select go to the (then idle) hit list; P > 1: a region of their own
+            const size_t cand = P > 1 ? (size_t)(P * nw * 16 + 16 + 2) * 8 : 0;
+            const size_t extra = 256 + cand;  // per-wave hit counters
+            const size_t min_list = P > 1 ? 66 : (size_t)(nw * 16 + 16 + 2);
+            if (budget < s_bytes + extra + min_list * 8) continue;
+            size_t cap = (budget - s_bytes - extra) / 8;
+            if (cap > 512) cap = 512;
+            g.list_cap = (uint32_t)cap & ~1u;
+            g.wgs_per_cu = wgs;
+            g.nw = nw;
+            g.n_pass = P;
+            g.s_stride = s_stride;
+            g.lds = s_bytes + (size_t)g.list_cap * 8 + extra;
+            return RK_OK;
+        }
     }
-    return fail(RK_ERR_UNSUPPORTED, "n_branches=%u: the score vector does not fit one CU's LDS (%zu B)", nb, db->lds_per_cu);
+    return fail(RK_ERR_UNSUPPORTED, "n_branches=%u: no score-vector window fits one CU's LDS (%zu B)", nb, db->lds_per_cu);
 }
 
 static int check_launchable(const rk_db *db) {
@@ -840,6 +868,7 @@ template <int BITS, int TM>
 static int launch_wg_v(const rk_db *db, const WgGeometry &g, PlaceArgs a, hipStream_t stream) {
     a.s_stride = g.s_stride;
     a.list_cap = g.list_cap;
+    a.n_pass = g.n_pass;
     uint64_t blocks = (uint64_t)db->cu_count * g.wgs_per_cu;
     if (blocks > a.n_reads) blocks = a.n_reads;
     if (!blocks) return RK_OK;
@@ -863,21 +892,39 @@ static int launch_wg(const rk_db *db, const WgGeometry &g, const PlaceArgs &a, h
 }
 
 template <int BITS, int TM>
-static int launch_ascii_v(const rk_db *db, const PlaceArgs &args, AmbArgs m, hipStream_t stream) {
-    // LDS: S[s_stride] + candidate list + Samb/Camb windows of `chunk` branches (several passes if the tree is large)
-    const size_t fixed = (size_t)args.s_stride * 4 + (size_t)ASCII_LIST_CAP * 8;
-    if (fixed + 8 * 64 > db->lds_per_cu)
-        return fail(RK_ERR_UNSUPPORTED, "n_branches=%u: the score vector does not fit one CU's LDS (%zu B)", db->info.n_branches, db->lds_per_cu);
-    size_t chunk = args.s_stride;
-    const size_t budget = 64 * 1024;  // prefer several waves per CU; grow only if a single pass would not fit
-    if (fixed + 8 * chunk > budget) {
-        size_t avail = (fixed + 8 * 64 <= budget ? budget : db->lds_per_cu) - fixed;
-        chunk = avail / 8;
-        if (chunk > args.s_stride) chunk = args.s_stride;
+static int launch_ascii_v(const rk_db *db, PlaceArgs args, AmbArgs m, hipStream_t stream) {
+    // LDS: S[s_stride] + candidate list + Samb/Camb windows of `chunk` branches.  S holds the whole tree while that leaves room
+    // for the list and a minimal Samb/Camb window (then large trees take several ambiguity passes over the alternatives);
+    // beyond that (about 39 000 branches) S itself becomes a window of the tree and the read is walked once per window.
+    const uint32_t nb = db->info.n_branches;
+    const size_t list_bytes = (size_t)ASCII_LIST_CAP * 8;
+    uint32_t s_win = nb;
+    size_t chunk;
+    const bool force_windows = db->indexed && getenv("RK_WG_PASSES") && atoi(getenv("RK_WG_PASSES")) > 1;  // same test knob
+    if (!force_windows && (size_t)((nb + 4) & ~3u) * 4 + list_bytes + 8 * 64 <= db->lds_per_cu) {
+        args.s_stride = (nb + 4) & ~3u;
+        const size_t fixed = (size_t)args.s_stride * 4 + list_bytes;
+        chunk = args.s_stride;
+        const size_t budget = 64 * 1024;  // prefer several waves per CU; grow only if a single pass would not fit
+        if (fixed + 8 * chunk > budget) {
+            size_t avail = (fixed + 8 * 64 <= budget ? budget : db->lds_per_cu) - fixed;
+            chunk = avail / 8;
+            if (chunk > args.s_stride) chunk = args.s_stride;
+        }
+    } else {
+        if (!db->indexed) return fail(RK_ERR_UNSUPPORTED, "internal: a slot-offset image with n_branches=%u", nb);
+        // 12 bytes per branch of the window (S + Samb + Camb): the window is as large as one CU allows, split evenly
+        const size_t per = (db->lds_per_cu - list_bytes - 64) / 12;
+        uint32_t n_win = (uint32_t)((nb + per - 1) / per);
+        if (force_windows && n_win < 3) n_win = 3;
+        s_win = ((nb + n_win - 1) / n_win + 3) & ~3u;
+        args.s_stride = s_win + 4;
+        chunk = s_win;
     }
     if (chunk == 0 || args.s_stride == 0) return fail(RK_ERR_INVALID, "internal: ambiguity kernel launched without a score-vector geometry");
     m.amb_chunk = (uint32_t)chunk;
-    const size_t lds = fixed + 8 * chunk;
+    m.s_win = s_win;
+    const size_t lds = (size_t)args.s_stride * 4 + list_bytes + 8 * chunk;
     const uint64_t groups = (args.n_reads + 63) / 64;
     uint64_t waves_cu = db->lds_per_cu / lds;
     if (waves_cu > 32) waves_cu = 32;
@@ -922,15 +969,19 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     if (db->indexed && db->lanes_per_read == 0) {
         WgGeometry wg;
         if (choose_wg_geometry(db, wg) != RK_OK) return "";
-        snprintf(buf, sizeof(buf), "place_wg_kernel<BITS=%u,%s,%s,U=%d> waves/WG=%u lds/WG=%zuB rows/batch=%u WGs/CU=%u",
+        snprintf(buf, sizeof(buf), "place_wg_kernel<BITS=%u,%s,%s,U=%d> waves/WG=%u lds/WG=%zuB rows/batch=%u WGs/CU=%u passes=%u",
                  db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_HASH ? "HASH" : "DIRECT8",
-                 db->info.rows_bytes < ROWS_FIT32_LIMIT ? "OFF32" : "OFF64", RK_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu);
+                 db->info.rows_bytes < ROWS_FIT32_LIMIT ? "OFF32" : "OFF64", RK_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu, wg.n_pass);
         m->kernel_name = buf;
         return m->kernel_name.c_str();
     }
     if (choose_geometry(db, 7, g) != RK_OK) return "";
-    snprintf(buf, sizeof(buf), "place_packed_kernel<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
-             g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
+    PlaceArgs probe{};
+    probe.words_per_read = 16;
+    // (the tile-pipelined variant serves packed records of <= 16 words, i.e. reads of <= 256 bases / 102 residues; longer
+    // records take place_packed_kernel with the same geometry)
+    snprintf(buf, sizeof(buf), "%s<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
+             use_pipelined16(db, g, probe) ? "place_packed16_kernel" : "place_packed_kernel", g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
              db->info.rows_bytes < ROWS_FIT32_LIMIT ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();

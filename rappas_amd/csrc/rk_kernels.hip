@@ -220,7 +220,7 @@ struct Cursor {
 // per lane.  list[cnt] must be a zero descriptor (sentinel).  SOA: rows are u16 branch[len] | f32 score[len].
 template <int G, bool WIDE, bool SOA>
 __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, int cnt, u32 li, int lii,
-                                             const unsigned char *rows, u32 &br, float &sc) {
+                                             const unsigned char *rows, u32 &br, float &sc, u32 s_lo = 0, u32 s_win = 0xFFFFu) {
     typedef typename OffsetT<WIDE>::type off_t;
     const bool need = c.rem <= 0;
     int hn = c.h + (need ? 1 : 0);
@@ -239,7 +239,10 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
         const off_t bo = ok ? (off_t)(c.cur + 2 * li) : (off_t)0;
         const off_t so = ok ? (off_t)(c.scur + 4 * li) : (off_t)0;
         const u32 b16 = *(const unsigned short *)(rows + bo);
-        br = (b16 == 0xFFFFu) ? 0u : (b16 + 1u) * 4u;  // raw id -> slot offset (0xFFFF = padding / reserved line 0)
+        // raw id -> slot offset inside the score-vector window [s_lo, s_lo + s_win) the caller holds in LDS (the whole tree unless
+        // it exceeds the LDS); 0xFFFF = padding / reserved line 0 and ids outside the window go to the scratch word
+        const u32 xw = b16 - s_lo;
+        br = (xw < s_win) ? (xw + 1u) * 4u : 0u;
         sc = *(const float *)(rows + so);
         c.cur += 2 * G;
         c.scur += 4 * G;
@@ -257,12 +260,13 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
 // S[x] update of PlacementProcess.java:726-733: first touch seeds fl(Q*T), then S = fl(S + fl(v - T)).
 // Branch-free: lanes without an entry (br == 0xFFFF) update the group's scratch word S[nb] instead, so the
 // compiler can overlap the LDS read latency with the address arithmetic of the next ring slot.
-__device__ __forceinline__ void apply_entry(u32 *S, u32 nb, u32 br, float sc, float QT, float T) {
+__device__ __forceinline__ void apply_entry(u32 *S, u32 nb, u32 br, float sc, float QT, float T, u32 br_base = 0) {
     if (RK_ABLATE & 8) {  // timing-only: keep the loads alive, skip the LDS update
         asm volatile("" ::"v"(br), "v"(sc));
         return;
     }
-    const u32 idx = (br != 0xFFFFu) ? br : nb;
+    // (S holds the branches [br_base, br_base + nb) of the pass; word nb is the scratch slot)
+    const u32 idx = (br != 0xFFFFu) ? br - br_base : nb;
     const u32 old = S[idx];
     const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
     const float d = sc - T;
@@ -290,19 +294,19 @@ __device__ __forceinline__ void apply_slot(u32 *S, u32 sb, float sc, float QT, f
 }
 template <int G, int U, bool WIDE, bool SOA = false>
 __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list, int cnt, u32 li,
-                                                const unsigned char *rows, float QT, float T) {
+                                                const unsigned char *rows, float QT, float T, u32 s_lo = 0, u32 s_win = 0xFFFFu) {
     Cursor<WIDE> c;
     c.h = -1; c.rem = 0; c.cur = 0; c.scur = 0;
     c.dn = list[0];
     u32 br[U];
     float sc[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u]);
+    for (int u = 0; u < U; u++) cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u], s_lo, s_win);
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             apply_slot(S, br[u], sc[u], QT, T);
-            cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u]);
+            cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u], s_lo, s_win);
         }
         if (!__any(c.h < cnt)) break;
     }
@@ -987,6 +991,249 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// place_packed16_kernel: the same algorithm as place_packed_kernel<16, ..., WIDE=false> for the geometry every BASELINE
+// small-tree config runs in (16 lanes per read, direct table, packed record of <= 16 words: 256 bases / 102 residues),
+// software-pipelined ACROSS tiles:
+//   * lane li of a group holds word li of its read's packed record -- ONE coalesced load per tile instead of two loads
+//     per k-mer position; DNA codes of the first 144 positions come out of it with DPP row broadcasts + v_alignbit;
+//   * the record of tile t+1 is loaded before the accumulate phase of tile t, its table gathers are issued before the
+//     select phase of tile t and decoded after it: the probe latency of a wave hides under its own select ALU time
+//     instead of relying on another wave's row gathers to fill it.
+// Results are identical to place_packed_kernel's (same emit order, same accumulate, same select).
+// ------------------------------------------------------------------------------------------------
+template <int LANE>
+__device__ __forceinline__ u32 row_bcast32(u32 v) {  // value of lane LANE of the caller's 16-lane row
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + LANE, 0xF, 0xF, false);  // row_newbcast:LANE
+}
+
+template <int PU, int U0>
+struct Batch0Words {
+    static __device__ __forceinline__ void run(u32 recw, u32 (&w)[PU + 1]) {
+        w[U0] = row_bcast32<U0>(recw);
+        Batch0Words<PU, U0 + 1>::run(recw, w);
+    }
+};
+template <int PU>
+struct Batch0Words<PU, PU> {
+    static __device__ __forceinline__ void run(u32 recw, u32 (&w)[PU + 1]) { w[PU] = row_bcast32<(PU < 16 ? PU : 15)>(recw); }
+};
+
+// k-mer codes of positions u*16 + li (u < PU) of a record held one word per lane (lanes >= words_per_read hold 0)
+template <int BITS, int PU>
+__device__ __forceinline__ void record_codes(u32 recw, u32 pos, u32 li, u32 k, u32 Q, u64 (&code)[PU]) {
+    if (BITS == 2 && PU <= 15) {
+        if (pos == 0) {  // (the usual batch: position u*16 + li starts in word u at bit 2*li)
+            u32 w[PU + 1];
+            Batch0Words<PU, 0>::run(recw, w);
+            const u32 mask = (k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+#pragma unroll
+            for (int u = 0; u < PU; u++) code[u] = __builtin_amdgcn_alignbit(w[u + 1], w[u], 2 * li) & mask;  // any bit pattern is a valid DNA code
+            return;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const u32 j0 = pos + u * 16 + li;
+        const u32 j = j0 < Q ? j0 : 0u;  // (AA: digits read past the read's end could be >= 20)
+        const u32 bit = j * BITS, wi = bit >> 5, sh = bit & 31;
+        const u32 w0 = __shfl(recw, (int)(wi & 15u), 16);
+        u32 w1 = __shfl(recw, (int)((wi + 1) & 15u), 16);
+        w1 = wi + 1 < 16 ? w1 : 0u;
+        u64 c = (((u64)w1 << 32) | w0) >> sh;
+        const u32 nbits = k * BITS;
+        if (BITS * 12 + 31 > 64) {
+            u32 w2 = __shfl(recw, (int)((wi + 2) & 15u), 16);
+            w2 = (wi + 2 < 16 && nbits + sh > 64) ? w2 : 0u;
+            c |= sh ? ((u64)w2 << (64 - sh)) : 0ull;
+        }
+        code[u] = nbits >= 64 ? c : (c & ((1ull << nbits) - 1));
+    }
+}
+
+template <int BITS, int TM, int U, int PU>
+__global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
+    constexpr int G = 16, NG = 4;
+    static_assert(TM != TM_HASH, "direct tables only");
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = threadIdx.x >> 6;
+    const u32 waves_per_block = blockDim.x >> 6;
+    const u32 gi = lane / G, li = lane % G;
+    const u32 wave_words = NG * (a.s_stride + 2 * a.list_cap);
+    u32 *wbase = lds + wave * wave_words;
+    u32 *S = wbase + gi * a.s_stride;
+    u64 *list = (u64 *)(wbase + NG * a.s_stride) + gi * a.list_cap;
+    u32 *items = (u32 *)list;
+    const u32 nb = a.db.n_branches;
+    const u32 k = a.db.k;
+    const float T = a.db.T;
+    const u64 gmask = (1ull << G) - 1;
+    const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
+    const int cap_items = (int)(a.list_cap * 2) - 3 * U - 2;
+    const int cap_rows = (int)a.list_cap - 1;
+    const u32 wpr = a.words_per_read;  // <= 16 (checked by the host)
+
+    for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
+    wave_lds_fence();
+
+    const u64 n_tiles = (a.n_reads + NG - 1) / NG;
+    const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
+    const u64 wave_count = (u64)gridDim.x * waves_per_block;
+
+    // per-tile inputs of a group: its record word, length, incoming flags
+    auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
+        const u64 r = tile * NG + gi;
+        have = tile < n_tiles && r < a.n_reads;
+        recw = 0; R = 0; fin = 0;
+        if (have) {
+            if (li < wpr) recw = a.packed[r * wpr + li];
+            R = a.lens ? a.lens[r] : a.fixed_len;
+            fin = a.flags_in ? a.flags_in[r] : 0u;
+        }
+    };
+    auto mer_count = [&](u32 R, u32 fin, bool have) -> u32 {  // Q = sk.getMerCount() (AmbigSequenceKnife.java:191)
+        const u32 cap_syms = (wpr * 32u) / BITS;
+        R = R < cap_syms ? R : cap_syms;
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        return (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
+    };
+    auto fetch_batch = [&](u32 recw, u32 pos, u32 Q, u64 (&code)[PU], RawSlot (&raw)[PU]) {
+        record_codes<BITS, PU>(recw, pos, li, k, Q, code);
+#pragma unroll
+        for (int u = 0; u < PU; u++) raw[u] = lookup_fetch<BITS, TM>(a.db, code[u]);
+    };
+    auto decode_batch = [&](const u64 (&code)[PU], const RawSlot (&raw)[PU], u32 pos, u32 Q, u64 (&desc)[PU]) {
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const u32 j = pos + u * G + li;
+            const u64 d = lookup_decode<BITS, TM>(a.db, raw[u], code[u]);
+            desc[u] = j < Q ? d : 0ull;
+        }
+    };
+
+    // prologue: the first tile's inputs and its first batch of descriptors
+    u32 c_recw, c_R, c_fin;
+    bool c_have;
+    u64 desc0[PU];
+    {
+        load_tile(wave_global, c_recw, c_R, c_fin, c_have);
+        u64 code[PU];
+        RawSlot raw[PU];
+        const u32 Q0 = mer_count(c_R, c_fin, c_have);
+        fetch_batch(c_recw, 0u, Q0, code, raw);
+        decode_batch(code, raw, 0u, Q0, desc0);
+    }
+
+    for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const u64 r = tile * NG + gi;
+        const bool have = c_have;
+        const u32 fin = c_fin;
+        u32 R = c_R;
+        {
+            const u32 cap_syms = (wpr * 32u) / BITS;
+            R = R < cap_syms ? R : cap_syms;
+        }
+        u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        if (R < k) flags |= RK_FLAG_TOO_SHORT;
+        const u32 Q = mer_count(c_R, fin, have);
+        const float QT = (float)(int)Q * T;  // int * float (PlacementProcess.java:728)
+
+        int cnt = 0;  // chunk items waiting in the list
+        auto flush = [&]() {
+            int wcnt = __builtin_amdgcn_readlane(cnt, 0);
+            wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 32));
+            wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 16));
+            wcnt = max(wcnt, __builtin_amdgcn_readlane(cnt, 48));
+            for (int i = cnt + (int)li; i < wcnt + 2 * U; i += G) items[i] = ITEM_FILLER;
+            wave_lds_fence();
+            if (a.db.mono) accumulate_units<G, U, true>(S, items, wcnt, li, rows_rs, QT, T);
+            else accumulate_units<G, U, false>(S, items, wcnt, li, rows_rs, QT, T);
+            wave_lds_fence();
+            cnt = 0;
+        };
+        // one batch of PU*16 positions: descriptors -> unit items in k-mer order (or, for rows too long for the list, the
+        // row-cursor fallback); identical to place_packed_kernel's emit phase
+        auto emit_batch = [&](const u64 (&desc)[PU], bool more) {
+            u32 nch[PU], excl[PU];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;
+                nch[u] = (lenp + G - 1) >> 4;
+                u32 incl = nch[u];
+                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);
+                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+                excl[u] = (u32)total + incl - nch[u];
+                total += (int)__shfl(incl, G - 1, G);
+            }
+            if (__any(more && cnt + total > cap_items)) flush();
+            if (__any(more && total > cap_items)) {
+                const int per_part = cap_rows / G;
+                for (int u_lo = 0; u_lo < PU; u_lo += per_part) {
+                    int rc = 0;
+#pragma unroll
+                    for (int u = 0; u < PU; u++) {
+                        const bool part = u >= u_lo && u < u_lo + per_part;
+                        const bool hit = part && ((u32)desc[u] & DESC_LEN_MASK) != 0;
+                        const u64 bal = __ballot(hit);
+                        const u64 sub = (bal >> (gi * G)) & gmask;
+                        if (hit) list[rc + __builtin_popcountll(sub & ((1ull << li) - 1))] = desc[u];
+                        rc += __builtin_popcountll(sub);
+                    }
+                    if (li == 0) list[rc] = 0;
+                    wave_lds_fence();
+                    if (__any(rc > 0)) accumulate_list<G, U, false>(S, nb, list, rc, li, a.db.rows, QT, T);
+                    wave_lds_fence();
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const u32 rb = (u32)(desc[u] >> DESC_LEN_BITS) * 8u;  // byte offset of the row (128-byte units)
+                    const int base = cnt + (int)excl[u];
+                    if (nch[u] > 0) items[base] = rb;
+                    if (nch[u] > 1) items[base + 1] = rb + 128u;
+                    for (u32 c = 2; __any(c < nch[u]); c++)
+                        if (c < nch[u]) items[base + (int)c] = rb + c * 128u;
+                }
+                cnt += total;
+            }
+        };
+
+        emit_batch(desc0, Q > 0);
+        for (u32 pos = PU * G; __any(pos < Q); pos += PU * G) {  // reads longer than PU*16 + k - 1 symbols
+            u64 code[PU], desc[PU];
+            RawSlot raw[PU];
+            fetch_batch(c_recw, pos, Q, code, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            decode_batch(code, raw, pos, Q, desc);
+            emit_batch(desc, pos < Q);
+        }
+        // next tile's inputs: in flight during this tile's accumulate phase
+        load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
+        if (__any(cnt > 0)) flush();
+        // next tile's first batch of table gathers: in flight during this tile's select phase
+        u64 ncode[PU];
+        RawSlot nraw[PU];
+        const u32 nQ = mer_count(c_R, c_fin, c_have);
+        fetch_batch(c_recw, 0u, nQ, ncode, nraw);
+        __builtin_amdgcn_sched_barrier(0);
+
+        u64 win_key;
+        const int numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
+        wave_lds_fence();
+        decode_batch(ncode, nraw, 0u, nQ, desc0);  // (before this tile's stores, so that the wait covers loads only)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+        if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // large trees: one WORKGROUP per read (place_wg_kernel)
 //
 // When S[n_branches] takes most of a CU's LDS (C5: 19 999 branches = 80 KB) a single wave per read leaves 2 waves
@@ -999,7 +1246,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
 constexpr int WG_SLOTS = 4;  // rows per lane in the slice table of a wave: a probe batch holds <= 64 * WG_SLOTS rows
 
 template <bool WIDE, int U>
-__device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list, int cnt, u32 lane, u32 q_lo, u32 q_hi,
+__device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, u32 base, const u64 *list, int cnt, u32 lane, u32 q_lo, u32 q_hi,
                                                 const unsigned char *rows, float QT, float T) {
     typedef typename OffsetT<WIDE>::type off_t;
     // ---- phase A: this wave's slice [start, start + n) of every row of the batch (row h lives in lane h%64, slot h/64)
@@ -1016,8 +1263,9 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
         const u32 lenp = (u32)d & DESC_LEN_MASK;
         const unsigned short *split = (const unsigned short *)(rows + off - 64);
         const u32 lo_raw = split[q_lo ? q_lo - 1 : 0];
-        const u32 hi = split[q_hi - 1];
+        const u32 hi_raw = split[q_hi ? q_hi - 1 : 0];
         const u32 lo = q_lo ? lo_raw : 0u;
+        const u32 hi = q_hi > q_lo ? hi_raw : lo;  // (a wave may own an empty range when waves outnumber the pass's splits)
         nn[sl] = have ? hi - lo : 0u;
         start[sl] = off + (off_t)lo * 2;
         sstart[sl] = off + (off_t)lenp * 2 + (off_t)lo * 4;
@@ -1077,7 +1325,7 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
         const bool was_done = done;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_entry(S, nb, br[u], sc[u], QT, T);
+            apply_entry(S, nb, br[u], sc[u], QT, T, base);
             gen(br[u], sc[u]);
         }
         if (was_done) break;  // everything issued since `done` was a skip and everything before it has been applied
@@ -1085,7 +1333,7 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, const u64 *list,
 }
 
 // exact top-K of the quads [q0, q1) of S by K rounds of "largest key below the previous winner" (rare fallback)
-__device__ __forceinline__ int select_rounds64(const u32 *S, u32 nb, u32 q0, u32 q1, u32 lane, int K, u64 &win_key) {
+__device__ __forceinline__ int select_rounds64(const u32 *S, u32 nb, u32 base, u32 q0, u32 q1, u32 lane, int K, u64 &win_key) {
     const uint4 *S4 = (const uint4 *)S;
     u64 prev = ~0ull;
     int num = 0;
@@ -1098,7 +1346,7 @@ __device__ __forceinline__ int select_rounds64(const u32 *S, u32 nb, u32 q0, u32
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const u32 i = 4 * q + e;
-                const u64 key = (raw[e] != S_UNTOUCHED && i < nb) ? make_key(raw[e], i) : 0ull;
+                const u64 key = (raw[e] != S_UNTOUCHED && i < nb) ? make_key(raw[e], i + base) : 0ull;
                 best = (key < prev && key > best) ? key : best;
             }
         }
@@ -1118,17 +1366,19 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
     u32 *S = lds;
     u64 *list = (u64 *)(lds + a.s_stride);
     u32 *wcnt = (u32 *)(list + a.list_cap);  // [NW] hits per wave of the current probe batch
+    // wave winners of every pass (level-2 select input): one pass -> the hit list, idle by then; several -> a region of their own
+    u64 *cand = a.n_pass == 1 ? list : (u64 *)(wcnt + 64);
     const u32 nb = a.db.n_branches, k = a.db.k;
     const float T = a.db.T;
     const int K = (int)a.keep_at_most;
     u32 batch = blockDim.x;  // k-mer positions probed per round: every hit must fit the list / the slice table
     if (batch > a.list_cap - 1) batch = a.list_cap - 1;
     if (batch > 64 * WG_SLOTS) batch = 64 * WG_SLOTS;
-    const u32 q_lo = wave * 32 / NW, q_hi = (wave + 1) * 32 / NW;  // branch range of this wave (index-line boundaries)
-    const u32 n4 = (nb + 3) / 4, n4_full = nb / 4;
-    const u32 qpw = (n4 + NW - 1) / NW;                             // quads of S this wave scans in the select phase
-    const u32 sq0 = wave * qpw < n4 ? wave * qpw : n4;
-    const u32 sq1 = sq0 + qpw < n4 ? sq0 + qpw : n4;
+    // Trees whose score vector exceeds one CU's LDS (the reference accepts ids up to 65 534, CustomHash_v4_FastUtil81.java:79,87)
+    // run n_pass passes over the read, each holding the branches of 32 / n_pass index-line ranges in S; every pass repeats
+    // the probe (cheap next to the rows it streams) and leaves its wave winners in `cand`; per-branch float order is untouched
+    // because a branch belongs to exactly one pass and one wave.
+    const u32 P = a.n_pass, span = 32u / P;
     uint4 *S4w = (uint4 *)S;
     const uint4 *S4 = (const uint4 *)S;
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
@@ -1148,82 +1398,92 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
         const float QT = (float)(int)Q * T;
         const u32 *rec = a.packed + r * a.words_per_read;
 
-        for (u32 pos0 = 0; pos0 < Q; pos0 += batch) {
-            // ---- probe: thread <-> k-mer position; hits compacted in position order across the workgroup ----
-            const u32 j = pos0 + tid;
-            const bool ok = tid < batch && j < Q;
-            u64 desc = 0;
-            if (TM != TM_HASH) {
-                const u64 d = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, ok ? j : 0u, k));
-                desc = ok ? d : 0ull;
-            } else if (ok) {
-                desc = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+        for (u32 pass = 0; pass < P; pass++) {
+            const u32 p_lo = pass * span, p_hi = (pass + 1) * span;
+            const u32 base = (u32)(((u64)p_lo * nb) / 32);          // first branch of the pass
+            const u32 win = (u32)(((u64)p_hi * nb) / 32) - base;    // branches of the pass (<= s_stride - 1)
+            const u32 q_lo = p_lo + wave * span / NW, q_hi = p_lo + (wave + 1) * span / NW;  // index-line ranges of this wave
+            const u32 n4 = (win + 3) / 4, n4_full = win / 4;
+            const u32 qpw = (n4 + NW - 1) / NW;                       // quads of S this wave scans in the select phase
+            const u32 sq0 = wave * qpw < n4 ? wave * qpw : n4;
+            const u32 sq1 = sq0 + qpw < n4 ? sq0 + qpw : n4;
+            for (u32 pos0 = 0; pos0 < Q; pos0 += batch) {
+                // ---- probe: thread <-> k-mer position; hits compacted in position order across the workgroup ----
+                const u32 j = pos0 + tid;
+                const bool ok = tid < batch && j < Q;
+                u64 desc = 0;
+                if (TM != TM_HASH) {
+                    const u64 d = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, ok ? j : 0u, k));
+                    desc = ok ? d : 0ull;
+                } else if (ok) {
+                    desc = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
+                }
+                const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
+                const u64 bal = __ballot(hit);
+                if (lane == 0) wcnt[wave] = (u32)__builtin_popcountll(bal);
+                __syncthreads();
+                u32 hbase = 0, cnt = 0;
+                for (u32 w = 0; w < NW; w++) {
+                    const u32 c = wcnt[w];
+                    hbase += w < wave ? c : 0u;
+                    cnt += c;
+                }
+                if (hit) list[hbase + __builtin_popcountll(bal & ((1ull << lane) - 1))] = desc;
+                __syncthreads();
+                // ---- accumulate: every wave applies its branch range of every row, rows in k-mer order ----
+                if (cnt > 0 && q_hi > q_lo) wave_accumulate<WIDE, U>(S, win, base, list, (int)cnt, lane, q_lo, q_hi, a.db.rows, QT, T);
+                __syncthreads();
             }
-            const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
-            const u64 bal = __ballot(hit);
-            if (lane == 0) wcnt[wave] = (u32)__builtin_popcountll(bal);
-            __syncthreads();
-            u32 base = 0, cnt = 0;
-            for (u32 w = 0; w < NW; w++) {
-                const u32 c = wcnt[w];
-                base += w < wave ? c : 0u;
-                cnt += c;
-            }
-            if (hit) list[base + __builtin_popcountll(bal & ((1ull << lane) - 1))] = desc;
-            __syncthreads();
-            // ---- accumulate: every wave applies its branch range of every row, rows in k-mer order ----
-            if (cnt > 0) wave_accumulate<WIDE, U>(S, nb, list, (int)cnt, lane, q_lo, q_hi, a.db.rows, QT, T);
-            __syncthreads();
-        }
 
-        // ---- select, level 1: every wave ranks its segment of S (three best per lane, K rounds of wave max) ----
-        float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
-        u32 i0 = 0xFFFFu, i1 = 0xFFFFu, i2 = 0xFFFFu;
-        auto feed = [&](float v, u32 idx, bool in) {
-            const bool g0 = in && v > s0, g1 = in && v > s1, g2 = in && v > s2;
-            const float drop = g2 ? s2 : (in ? v : -INFINITY);
-            lost = fmaxf(lost, drop);
-            s2 = g1 ? s1 : (g2 ? v : s2);
-            i2 = g1 ? i1 : (g2 ? idx : i2);
-            s1 = g0 ? s0 : (g1 ? v : s1);
-            i1 = g0 ? i0 : (g1 ? idx : i1);
-            s0 = g0 ? v : s0;
-            i0 = g0 ? idx : i0;
-        };
-        for (u32 q = sq0 + lane; q < sq1; q += 64) {
-            const uint4 v4 = S4[q];
-            const u32 i = 4 * q;
-            const bool full = q < n4_full;
-            feed(__uint_as_float(v4.x), i, full || i < nb);
-            feed(__uint_as_float(v4.y), i + 1, full || i + 1 < nb);
-            feed(__uint_as_float(v4.z), i + 2, full || i + 2 < nb);
-            feed(__uint_as_float(v4.w), i + 3, full || i + 3 < nb);
+            // ---- select, level 1: every wave ranks its segment of S (three best per lane, K rounds of wave max) ----
+            float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
+            u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
+            auto feed = [&](float v, u32 idx, bool in) {
+                const bool g0 = in && v > s0, g1 = in && v > s1, g2 = in && v > s2;
+                const float drop = g2 ? s2 : (in ? v : -INFINITY);
+                lost = fmaxf(lost, drop);
+                s2 = g1 ? s1 : (g2 ? v : s2);
+                i2 = g1 ? i1 : (g2 ? idx : i2);
+                s1 = g0 ? s0 : (g1 ? v : s1);
+                i1 = g0 ? i0 : (g1 ? idx : i1);
+                s0 = g0 ? v : s0;
+                i0 = g0 ? idx : i0;
+            };
+            for (u32 q = sq0 + lane; q < sq1; q += 64) {
+                const uint4 v4 = S4[q];
+                const u32 i = 4 * q;
+                const bool full = q < n4_full;
+                feed(__uint_as_float(v4.x), i, full || i < win);
+                feed(__uint_as_float(v4.y), i + 1, full || i + 1 < win);
+                feed(__uint_as_float(v4.z), i + 2, full || i + 2 < win);
+                feed(__uint_as_float(v4.w), i + 3, full || i + 3 < win);
+            }
+            u64 k0 = (i0 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s0), i0 + base) : 0ull;
+            u64 k1 = (i1 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s1), i1 + base) : 0ull;
+            u64 k2 = (i2 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s2), i2 + base) : 0ull;
+            u64 wkey = 0, last = 0;
+            int num = 0;
+            for (int rr = 0; rr < K; rr++) {
+                const u64 mx = group_max<64>(k0);
+                if (mx == 0) break;
+                num++;
+                last = mx;
+                if (k0 == mx) { k0 = k1; k1 = k2; k2 = 0; }
+                if ((int)lane == rr) wkey = mx;
+            }
+            const bool doubt = (num == K) ? (lost >= unord_f32((u32)(last >> 32))) : (lost > -INFINITY);
+            if (__any(doubt)) num = select_rounds64(S, win, base, sq0, sq1, lane, K, wkey);
+            for (u32 q = sq0 + lane; q < sq1; q += 64) S4w[q] = reset4;
+            if ((int)lane < K) cand[(pass * NW + wave) * K + lane] = ((int)lane < num) ? wkey : 0ull;
+            __syncthreads();
         }
-        u64 k0 = (i0 != 0xFFFFu) ? make_key(__float_as_uint(s0), i0) : 0ull;
-        u64 k1 = (i1 != 0xFFFFu) ? make_key(__float_as_uint(s1), i1) : 0ull;
-        u64 k2 = (i2 != 0xFFFFu) ? make_key(__float_as_uint(s2), i2) : 0ull;
-        u64 wkey = 0, last = 0;
-        int num = 0;
-        for (int rr = 0; rr < K; rr++) {
-            const u64 mx = group_max<64>(k0);
-            if (mx == 0) break;
-            num++;
-            last = mx;
-            if (k0 == mx) { k0 = k1; k1 = k2; k2 = 0; }
-            if ((int)lane == rr) wkey = mx;
-        }
-        const bool doubt = (num == K) ? (lost >= unord_f32((u32)(last >> 32))) : (lost > -INFINITY);
-        if (__any(doubt)) num = select_rounds64(S, nb, sq0, sq1, lane, K, wkey);
-        for (u32 q = sq0 + lane; q < sq1; q += 64) S4w[q] = reset4;
-        if ((int)lane < K) list[wave * K + lane] = ((int)lane < num) ? wkey : 0ull;
-        __syncthreads();
-        // ---- select, level 2 (wave 0): exact top-K of the NW*K wave winners, then weights and output rows ----
+        // ---- select, level 2 (wave 0): exact top-K of the n_pass*NW*K wave winners, then weights and output rows ----
         if (wave == 0) {
-            const int c = (int)NW * K;
-            u64 *win = list + ((c + 1) & ~1);
+            const int c = (int)(P * NW) * K;
+            u64 *win = cand + ((c + 1) & ~1);
             if ((int)lane < K) win[lane] = 0ull;
             wave_lds_fence();
-            rank_candidates<64>(list, c, win, K, lane);
+            rank_candidates<64>(cand, c, win, K, lane);
             const u64 win_key = ((int)lane < K) ? win[lane] : 0ull;
             const int numBest = __builtin_popcountll(__ballot(win_key != 0));
             const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
@@ -1249,6 +1509,7 @@ struct AmbArgs {
     u32 amb_mode;
     u32 max_amb;
     u32 amb_chunk;  // branches covered by the LDS Samb/Camb windows per pass (== s_stride when everything fits)
+    u32 s_win;      // branches of the tree the score vector S holds per pass over the read (>= n_branches unless the tree exceeds the LDS)
 };
 
 // One ambiguous k-mer (exactly one ambiguous position p of class cls): PlacementProcess.java:1129-1236.
@@ -1257,10 +1518,12 @@ struct AmbArgs {
 template <int BITS, int TM>
 __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &m, u32 *S, float *Samb, u32 *Camb,
                                              u32 chunk, u64 code, u32 p, u32 cls, u32 lane, float QT, bool have_pre,
-                                             const u64 (&pre)[4]) {
-    const u32 nb = a.db.n_branches;
+                                             const u64 (&pre)[4], u32 s_lo, u32 nb) {
+    // S, Samb and Camb hold the branches [s_lo, s_lo + nb) of the tree (the whole tree unless it exceeds the LDS: then the read
+    // is walked once per window); ids outside the window are dropped right after they are loaded
     const float T = a.db.T, P = a.db.P;
     const u32 W = m.alt_count[cls];
+    auto rebase = [&](u32 &x) { const u32 xw = x - s_lo; x = (xw < nb) ? xw : 0xFFFFu; };  // (padding 0xFFFF stays 0xFFFF)
     if (W <= 4 && chunk >= nb) {
         // fast path (DNA: <= 4 alternatives; one Samb/Camb window covers the tree): the alternatives' descriptors are
         // looked up together and, when every row fits the wave, their entries are loaded once into registers; the
@@ -1282,6 +1545,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
             u32 x = 0xFFFFu;
             float v = 0.0f;
             if (w < W && e < ((u32)dw & DESC_LEN_MASK)) load_entry(a.db, dw, e, x, v);
+            rebase(x);
             const bool have = x != 0xFFFFu;
             const double pw = (have && m.amb_mode == RK_AMB_MEAN) ? exp10((double)v) : 0.0;
 #pragma unroll
@@ -1342,6 +1606,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 xb[w] = 0xFFFFu;
                 v[w] = 0.0f;
                 if (lane < ((u32)d[w] & DESC_LEN_MASK)) load_entry(a.db, d[w], lane, xb[w], v[w]);
+                rebase(xb[w]);
             }
 #pragma unroll
             for (int w = 0; w < 4; w++) {  // pass 1 (:1139-1157 / :1198-1219)
@@ -1398,8 +1663,9 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 u32 xb0;
                 float v;
                 load_entry(a.db, desc, e, xb0, v);
+                rebase(xb0);
                 const u32 x = xb0 - lo;
-                if (x >= chunk) continue;  // other pass (also catches x < lo by wrap-around, and pad entries)
+                if (xb0 == 0xFFFFu || x >= chunk) continue;  // pad / outside the window; other chunk pass (x < lo wraps around)
                 u32 c = Camb[x];
                 Camb[x] = c + 1;
                 if (m.amb_mode == RK_AMB_MEAN) {
@@ -1423,8 +1689,9 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 u32 xb;
                 float vunused;
                 load_entry(a.db, desc, e, xb, vunused);
+                rebase(xb);
                 const u32 x = xb - lo;
-                if (x >= chunk) continue;  // also skips pad entries (0xFFFF >= any chunk window)
+                if (xb == 0xFFFFu || x >= chunk) continue;
                 u32 c = Camb[x];
                 if (c != 0) {
                     u32 old = S[xb + 1];
@@ -1457,9 +1724,13 @@ template <int BITS, int TM, bool SOA>
 __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m) {
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
-    const u32 nb = a.db.n_branches;
+    const u32 nb_tree = a.db.n_branches;
     u32 *S = lds;
-    // Samb/Camb cover branches [lo, lo + amb_chunk) per pass; large trees take several passes over the alternatives
+    // S covers the branches [s_lo, s_lo + s_win) of the tree: the whole tree in one pass over the read, or -- trees beyond the
+    // LDS (the reference accepts ids up to 65 534) -- one pass per window, each leaving its K best for a final merge.
+    // Samb/Camb cover `chunk` branches of that window per ambiguity pass.
+    const u32 s_win = m.s_win < nb_tree ? m.s_win : nb_tree;
+    const u32 n_win = (nb_tree + s_win - 1) / s_win;
     const u32 chunk = m.amb_chunk;
     u64 *clist = (u64 *)(lds + a.s_stride);  // ASCII_LIST_CAP slots: hit list, then candidate list of select_topk
     float *Samb = (float *)(lds + a.s_stride + 2 * ASCII_LIST_CAP);
@@ -1467,6 +1738,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     const u32 k = a.db.k;
     const float T = a.db.T;
     const int cap = ASCII_LIST_CAP - 1;
+    const int K = (int)a.keep_at_most;
     const bool fit32 = a.db.rows_bytes < ROWS_FIT32_LIMIT;
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     for (u32 i = lane; i < a.s_stride; i += 64) S[i] = S_UNTOUCHED;
@@ -1489,112 +1761,130 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
             if (R < k) flags |= RK_FLAG_TOO_SHORT;
             const u32 Q = R >= k ? R - k + 1 : 0;
             const float QT = (float)(int)Q * T;
-            int cnt = 0;
-            bool any_long = false;  // a pending row of more than 64 entries (more than one chunk of this 64-lane group)
-            auto flush = [&]() {
-                if (cnt > 0) {
-                    if (!SOA && fit32 && !any_long && !(RK_ABLATE & 256)) {
-                        // the usual case: every pending row is one chunk -> the buffer-addressed unit path of the packed kernel
-                        // (descriptors turned into unit items in place: every lane first reads its <= 3 descriptors)
-                        u64 dreg[3];
+            u64 acc_key = 0;  // lane r < K: rank-r winner over the windows done so far
+            for (u32 wi = 0; wi < n_win; wi++) {
+                const u32 s_lo = wi * s_win;
+                const u32 nb = nb_tree - s_lo < s_win ? nb_tree - s_lo : s_win;  // branches of this window
+                int cnt = 0;
+                bool any_long = false;  // a pending row of more than 64 entries (more than one chunk of this 64-lane group)
+                auto flush = [&]() {
+                    if (cnt > 0) {
+                        if (!SOA && fit32 && !any_long && !(RK_ABLATE & 256)) {
+                            // the usual case: every pending row is one chunk -> the buffer-addressed unit path of the packed kernel
+                            // (descriptors turned into unit items in place: every lane first reads its <= 3 descriptors)
+                            // (slot-offset images are only built for trees that fit the LDS whole: s_lo == 0 here)
+                            u64 dreg[3];
 #pragma unroll
-                        for (int t = 0; t < 3; t++) dreg[t] = ((int)lane + 64 * t < cnt) ? clist[lane + 64 * t] : 0ull;
-                        wave_lds_fence();
-                        u32 *items = (u32 *)clist;
+                            for (int t = 0; t < 3; t++) dreg[t] = ((int)lane + 64 * t < cnt) ? clist[lane + 64 * t] : 0ull;
+                            wave_lds_fence();
+                            u32 *items = (u32 *)clist;
 #pragma unroll
-                        for (int t = 0; t < 3; t++)
-                            if ((int)lane + 64 * t < cnt)
-                                items[lane + 64 * t] = ((u32)(dreg[t] >> DESC_LEN_BITS) * 8u) | ((((u32)dreg[t] & DESC_LEN_MASK) >> 4) - 1u);
-                        for (int i = cnt + (int)lane; i < cnt + 2 * RK_ASCII_RING; i += 64) items[i] = ITEM_FILLER;
+                            for (int t = 0; t < 3; t++)
+                                if ((int)lane + 64 * t < cnt)
+                                    items[lane + 64 * t] = ((u32)(dreg[t] >> DESC_LEN_BITS) * 8u) | ((((u32)dreg[t] & DESC_LEN_MASK) >> 4) - 1u);
+                            for (int i = cnt + (int)lane; i < cnt + 2 * RK_ASCII_RING; i += 64) items[i] = ITEM_FILLER;
+                            wave_lds_fence();
+                            if (a.db.mono) accumulate_units<64, RK_ASCII_RING, true>(S, items, cnt, lane, rows_rs, QT, T);
+                            else accumulate_units<64, RK_ASCII_RING, false>(S, items, cnt, lane, rows_rs, QT, T);
+                            wave_lds_fence();
+                            cnt = 0;
+                            return;
+                        }
+                        if (lane == 0) clist[cnt] = 0;  // sentinel: an empty row ends the cursor
                         wave_lds_fence();
-                        if (a.db.mono) accumulate_units<64, RK_ASCII_RING, true>(S, items, cnt, lane, rows_rs, QT, T);
-                        else accumulate_units<64, RK_ASCII_RING, false>(S, items, cnt, lane, rows_rs, QT, T);
+                        if (!(RK_ABLATE & 256)) accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T, s_lo, SOA ? nb : 0xFFFFu);
                         wave_lds_fence();
                         cnt = 0;
-                        return;
+                        any_long = false;
                     }
-                    if (lane == 0) clist[cnt] = 0;  // sentinel: an empty row ends the cursor
-                    wave_lds_fence();
-                    if (!(RK_ABLATE & 256)) accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T);
-                    wave_lds_fence();
-                    cnt = 0;
-                    any_long = false;
-                }
-            };
-            for (u32 j0 = 0; j0 < Q; j0 += 64) {
-                const u32 j = j0 + lane;
-                const bool inr = j < Q;
-                u64 code = 0;      // ambiguous positions contribute state 0
-                u32 ambmask = 0;   // bit i <=> window position i is ambiguous
-                if (inr) {
-                    for (u32 i = 0; i < k; i++) {
-                        const u32 c = m.char_table[s[j + i]];
-                        code |= (u64)((c & 0x80) ? 0u : c) << (BITS * i);
-                        ambmask |= ((c >> 7) & 1u) << i;
+                };
+                for (u32 j0 = 0; j0 < Q; j0 += 64) {
+                    const u32 j = j0 + lane;
+                    const bool inr = j < Q;
+                    u64 code = 0;      // ambiguous positions contribute state 0
+                    u32 ambmask = 0;   // bit i <=> window position i is ambiguous
+                    if (inr) {
+                        for (u32 i = 0; i < k; i++) {
+                            const u32 c = m.char_table[s[j + i]];
+                            code |= (u64)((c & 0x80) ? 0u : c) << (BITS * i);
+                            ambmask |= ((c >> 7) & 1u) << i;
+                        }
                     }
-                }
-                u64 desc = 0;
-                if (inr && ambmask == 0) desc = lookup_desc<BITS, TM>(a.db, code);
-                const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
-                // one ambiguous character puts k consecutive positions on the ambiguity path: their alternatives (<= 4 each for
-                // DNA) are looked up here for all of them at once, one lane per position, instead of one position at a time
-                u64 alt_d[4] = {0ull, 0ull, 0ull, 0ull};
-                const bool one_amb = inr && __builtin_popcount(ambmask) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP;
-                bool pre_ok = false;
-                if (one_amb) {
-                    const u32 p = __builtin_ctz(ambmask);
-                    const u32 cls = m.char_table[s[j + p]] & 0x7F;
-                    const u32 W = m.alt_count[cls];
-                    if (W <= 4) {
-                        pre_ok = true;
+                    u64 desc = 0;
+                    if (inr && ambmask == 0) desc = lookup_desc<BITS, TM>(a.db, code);
+                    const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
+                    // one ambiguous character puts k consecutive positions on the ambiguity path: their alternatives (<= 4 each for
+                    // DNA) are looked up here for all of them at once, one lane per position, instead of one position at a time
+                    u64 alt_d[4] = {0ull, 0ull, 0ull, 0ull};
+                    const bool one_amb = inr && __builtin_popcount(ambmask) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP;
+                    bool pre_ok = false;
+                    if (one_amb) {
+                        const u32 p = __builtin_ctz(ambmask);
+                        const u32 cls = m.char_table[s[j + p]] & 0x7F;
+                        const u32 W = m.alt_count[cls];
+                        if (W <= 4) {
+                            pre_ok = true;
 #pragma unroll
-                        for (int w = 0; w < 4; w++)
-                            if ((u32)w < W) alt_d[w] = lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p)));
+                            for (int w = 0; w < 4; w++)
+                                if ((u32)w < W) alt_d[w] = lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p)));
+                        }
+                    }
+                    u64 amb_b = __ballot(inr && ambmask != 0);
+                    const u64 hit_b = __ballot(hit);
+                    u32 p0 = 0;
+                    while (true) {  // wave-uniform: runs of unambiguous positions separated by ambiguous ones
+                        const u32 na = amb_b ? (u32)__builtin_ctzll(amb_b) : 64u;
+                        const u64 below_na = na >= 64 ? ~0ull : ((1ull << na) - 1);
+                        const u64 hb = hit_b & below_na & ~((1ull << p0) - 1);
+                        const int nh = __builtin_popcountll(hb);
+                        if (cnt + nh > cap) flush();
+                        if ((hb >> lane) & 1ull) clist[cnt + __builtin_popcountll(hb & ((1ull << lane) - 1))] = desc;
+                        cnt += nh;
+                        any_long = any_long || __any(((hb >> lane) & 1ull) && ((u32)desc & DESC_LEN_MASK) > 64u);
+                        if (na >= 64) break;
+                        flush();  // everything before the ambiguous k-mer must be applied first
+                        const u32 maskA = (u32)__builtin_amdgcn_readlane((int)ambmask, (int)na);
+                        const u32 clo = (u32)__builtin_amdgcn_readlane((int)(u32)code, (int)na);
+                        const u32 chi = (u32)__builtin_amdgcn_readlane((int)(u32)(code >> 32), (int)na);
+                        const u64 codeA = ((u64)chi << 32) | clo;
+                        if (__builtin_popcount(maskA) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP) {
+                            const u32 p = __builtin_ctz(maskA);
+                            const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
+                            const bool have_pre = __builtin_amdgcn_readlane((int)pre_ok, (int)na) != 0;
+                            u64 pre[4];
+#pragma unroll
+                            for (int w = 0; w < 4; w++)
+                                pre[w] = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(alt_d[w] >> 32), (int)na) << 32) |
+                                         (u32)__builtin_amdgcn_readlane((int)(u32)alt_d[w], (int)na);
+                            if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT, have_pre, pre, s_lo, nb);
+                        }
+                        amb_b &= amb_b - 1;
+                        p0 = na + 1;
+                        if (p0 >= 64) break;
                     }
                 }
-                u64 amb_b = __ballot(inr && ambmask != 0);
-                const u64 hit_b = __ballot(hit);
-                u32 p0 = 0;
-                while (true) {  // wave-uniform: runs of unambiguous positions separated by ambiguous ones
-                    const u32 na = amb_b ? (u32)__builtin_ctzll(amb_b) : 64u;
-                    const u64 below_na = na >= 64 ? ~0ull : ((1ull << na) - 1);
-                    const u64 hb = hit_b & below_na & ~((1ull << p0) - 1);
-                    const int nh = __builtin_popcountll(hb);
-                    if (cnt + nh > cap) flush();
-                    if ((hb >> lane) & 1ull) clist[cnt + __builtin_popcountll(hb & ((1ull << lane) - 1))] = desc;
-                    cnt += nh;
-                    any_long = any_long || __any(((hb >> lane) & 1ull) && ((u32)desc & DESC_LEN_MASK) > 64u);
-                    if (na >= 64) break;
-                    flush();  // everything before the ambiguous k-mer must be applied first
-                    const u32 maskA = (u32)__builtin_amdgcn_readlane((int)ambmask, (int)na);
-                    const u32 clo = (u32)__builtin_amdgcn_readlane((int)(u32)code, (int)na);
-                    const u32 chi = (u32)__builtin_amdgcn_readlane((int)(u32)(code >> 32), (int)na);
-                    const u64 codeA = ((u64)chi << 32) | clo;
-                    if (__builtin_popcount(maskA) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP) {
-                        const u32 p = __builtin_ctz(maskA);
-                        const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
-                        const bool have_pre = __builtin_amdgcn_readlane((int)pre_ok, (int)na) != 0;
-                        u64 pre[4];
-#pragma unroll
-                        for (int w = 0; w < 4; w++)
-                            pre[w] = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(alt_d[w] >> 32), (int)na) << 32) |
-                                     (u32)__builtin_amdgcn_readlane((int)(u32)alt_d[w], (int)na);
-                        if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT, have_pre, pre);
-                    }
-                    amb_b &= amb_b - 1;
-                    p0 = na + 1;
-                    if (p0 >= 64) break;
+                flush();
+                wave_lds_fence();
+                u64 win_key;
+#ifdef RK_STAMPS
+                unsigned long long st_[16] = {0}, t_ = 0;
+#endif
+                select_topk<64>(S, nb, lane, 0u, K, clist, ASCII_LIST_CAP, win_key RK_STAMP_ARGS);
+                wave_lds_fence();
+                if (win_key != 0) win_key -= s_lo;  // the key's low 16 bits hold 0xFFFF - branch: window-relative -> tree id
+                if (n_win == 1) {
+                    acc_key = win_key;
+                } else {  // merge this window's K best with the K best so far (keys are unique: they embed the branch id)
+                    if (lane < 16) { clist[lane] = acc_key; clist[16 + lane] = win_key; }
+                    if (lane < 16) clist[64 + lane] = 0ull;
+                    wave_lds_fence();
+                    rank_candidates<64>(clist, 32, clist + 64, K, lane);
+                    acc_key = ((int)lane < K) ? clist[64 + lane] : 0ull;
+                    wave_lds_fence();
                 }
             }
-            flush();
-            wave_lds_fence();
-            u64 win_key;
-#ifdef RK_STAMPS
-            unsigned long long st_[16] = {0}, t_ = 0;
-#endif
-            int numBest = select_topk<64>(S, nb, lane, 0u, (int)a.keep_at_most, clist, ASCII_LIST_CAP, win_key RK_STAMP_ARGS);
-            wave_lds_fence();
-            weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
+            const int numBest = __builtin_popcountll(__ballot(acc_key != 0));
+            weigh_and_store<64>(a, r, lane, numBest, acc_key, flags);
         }
     }
 }

@@ -184,12 +184,22 @@ class SynthSpec:
         else:
             hi = np.maximum(1, self.n_branches - lens).astype(np.uint64)
             b0 = 1 + (((_mix(h0 ^ np.uint64(0xE7037ED1A0B428DB)) >> np.uint64(32)) * hi) >> np.uint64(32)).astype(np.int64)
-        within = np.arange(total, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
-        branch = (np.repeat(b0, lens) + within).astype(np.uint16)
-        with np.errstate(over="ignore"):
-            hs = _mix(np.repeat(h0, lens) + (within.astype(np.uint64) + np.uint64(1)) * np.uint64(0xD6E8FEB86659FD93))
-        u = (hs >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
-        scores = (np.float32(self.thr_log10) * u).astype(np.float32)
+        branch = np.empty(total, dtype=np.uint16)
+        scores = np.empty(total, dtype=np.float32)
+        # in slices of ~3e7 entries: the temporaries are 8-byte arrays, the result 6 bytes per entry
+        a = 0
+        while a < n:
+            b = int(np.searchsorted(off, off[a] + np.uint64(30_000_000), side="right"))
+            b = min(n, max(a + 1, b - 1))
+            lo, hi_e = int(off[a]), int(off[b])
+            ln = lens[a:b]
+            within = np.arange(hi_e - lo, dtype=np.int64) - np.repeat((off[a:b] - off[a]).astype(np.int64), ln)
+            branch[lo:hi_e] = np.repeat(b0[a:b], ln) + within
+            with np.errstate(over="ignore"):
+                hs = _mix(np.repeat(h0[a:b], ln) + (within.astype(np.uint64) + np.uint64(1)) * np.uint64(0xD6E8FEB86659FD93))
+            u = (hs >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+            scores[lo:hi_e] = np.float32(self.thr_log10) * u
+            a = b
         return off, branch, scores
 
     def subset_db(self, dense):

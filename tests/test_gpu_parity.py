@@ -463,3 +463,45 @@ def test_host_path_across_chunk_boundaries():
         assert np.array_equal(rev.flags[::-1], got.flags)
     finally:
         db.close()
+
+
+# ---- trees beyond one CU's LDS: branch-range passes (the reference's limit is the 16-bit node id, 65 534) ----
+def _big_tree_db(n_branches, mean_row, seed=11):
+    n_keys = 3000
+    return synth.make_db(4, 6, n_branches, n_keys, int(n_keys * mean_row), seed=seed)
+
+
+@pytest.mark.parametrize("mean_row", [12, 400])
+@pytest.mark.parametrize("amb", ["mean", "max", "skip"])
+def test_tree_at_the_reference_limit(mean_row, amb):
+    """n_branches = 65 535 (ids up to 65 534, CustomHash_v4_FastUtil81.java:79,87): S is 262 KB, so the workgroup kernel runs
+    two branch-range passes per read and the ambiguity kernel five score-vector windows"""
+    sdb = _big_tree_db(65535, mean_row)
+    assert int(sdb.branch_ids.max()) > 60000
+    seq, off = synth.make_reads(4, 300, 150, seed=3, amb_rate=0.004, var_len=40)
+    got, ref, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct8", 0, amb)
+    assert st["placed"] > 250
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "passes=2" in db.kernel_name()
+    db.close()
+
+
+@pytest.mark.parametrize("n_branches", [39001, 50000])
+def test_trees_between_one_and_two_lds(n_branches):
+    sdb = _big_tree_db(n_branches, 60)
+    seq, off = synth.make_reads(4, 200, 150, seed=4, amb_rate=0.002)
+    _, _, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "hash", 0, "mean")
+    assert st["placed"] > 150
+
+
+@pytest.mark.parametrize("passes", ["2", "4"])
+def test_forced_passes_equal_the_single_pass_result(passes, monkeypatch):
+    """a C5-sized tree (19 999 branches fits one pass) run with 2 and 4 forced passes: identical placements"""
+    sdb = _big_tree_db(19999, 300, seed=5)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_reads(4, 300, 200, seed=6, amb_rate=0.003)
+    one, _, _ = run_case(sdb, odb, seq, off, "direct8", 0, "mean")
+    monkeypatch.setenv("RK_WG_PASSES", passes)
+    many, _, _ = run_case(sdb, odb, seq, off, "direct8", 0, "mean")
+    assert np.array_equal(one.branch, many.branch) and np.array_equal(one.score.view(np.uint32), many.score.view(np.uint32))
+    assert np.array_equal(one.n_rows, many.n_rows) and np.array_equal(one.lwr, many.lwr)
