@@ -162,7 +162,9 @@ int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_
  * on different devices (rk_db_create with desc.device = g); the batch is cut into n_dbs contiguous shards, shard g goes to
  * dbs[g] on its own host thread, and every shard writes its slice of the caller's result arrays -- reads are independent
  * (PlacementProcess.java:1067-1075 resets all per-read state), so there is no exchange step and no collective.  Results are
- * identical to one rk_place_batch call over the whole batch. */
+ * identical to one rk_place_batch call over the whole batch.  If a shard's device fails (a HIP error, out of memory) the shard is
+ * placed again on the handles that finished, in a fresh host thread; the call then still returns RK_OK and rk_last_error()
+ * names the device that dropped out ("" when nothing failed).  The call fails only when no healthy device is left for a shard. */
 int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                          const uint64_t *seq_off, rk_result *out, rk_counters *counters);
 

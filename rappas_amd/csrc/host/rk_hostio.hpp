@@ -135,6 +135,23 @@ inline void dedup_reads(const std::vector<Fasta> &recs, std::vector<Fasta> &uniq
     }
 }
 
+// notplaced_<query>.tsv (Main_PLACEMENT_v07.java:214, PlacementProcess.java:797-806): the full header of every read that hits
+// nothing in the database, every occurrence (the reference registers checksums of placed reads only, :1046), in file order
+inline std::string notplaced_log(const std::vector<Fasta> &recs, const std::vector<Fasta> &unique, const uint32_t *flags) {
+    std::map<std::array<uint8_t, 16>, size_t> index;
+    auto key_of = [](const std::string &seq) {
+        std::string nogap;
+        for (char c : seq)
+            if (c != '-') nogap.push_back(c);
+        return md5(nogap);
+    };
+    for (size_t i = 0; i < unique.size(); i++) index[key_of(unique[i].seq)] = i;
+    std::string out;
+    for (const Fasta &f : recs)
+        if (!(flags[index.at(key_of(f.seq))] & 1u)) { out += f.header; out += "\n"; }
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // N1: tree
 // ------------------------------------------------------------------------------------------------------------------

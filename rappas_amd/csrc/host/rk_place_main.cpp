@@ -2,6 +2,7 @@
 // The reference's `-p p` phase for one query file (src/main_v2/Main_PLACEMENT_v07.java:150-320): ingest and the jplace writer
 // are rk_hostio.hpp, the placement itself is rk_place_batch (GPU; there is no CPU fallback).
 // Same options and byte-identical output as `python -m rappas_amd.tools.place`.
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -19,14 +20,15 @@ static std::string slurp(const std::string &path) {
 
 static int usage() {
     std::cerr << "usage: rk_place --jsondb DB.json --fasta READS.fa --out OUT.jplace [--keep-at-most 7] [--keep-factor 0.01]\n"
-                 "                [--amb mean|max|skip] [--nsbound X] [--guppy-compat] [--device 0]\n"
+                 "                [--amb mean|max|skip] [--nsbound X] [--guppy-compat] [--device 0] [--logs DIR]\n"
                  "       rk_place --emit-tree TREE.nwk | --format-float X | --format-double X | --dedup READS.fa | --md5 TEXT\n";
     return 2;
 }
 
 int main(int argc, char **argv) {
     try {
-        std::string jsondb, fasta, out, amb = "mean";
+        std::string jsondb, fasta, out, amb = "mean", logs;
+        bool logs_given = false;
         uint32_t keep_at_most = 7;
         float keep_factor = 0.01f, nsbound = -INFINITY;
         bool guppy = false;
@@ -45,6 +47,7 @@ int main(int argc, char **argv) {
             else if (a == "--nsbound") nsbound = std::stof(val());
             else if (a == "--guppy-compat") guppy = true;
             else if (a == "--device") device = std::stoi(val());
+            else if (a == "--logs") { logs = val(); logs_given = true; }
             // ---- host-side pieces on their own (no device needed): used by the CPU tests ----
             else if (a == "--emit-tree") {
                 const rkh::Tree t = rkh::parse_newick(slurp(val()));
@@ -99,7 +102,8 @@ int main(int argc, char **argv) {
 
         std::vector<rkh::Fasta> uniq;
         std::vector<std::vector<std::string>> names;
-        rkh::dedup_reads(rkh::read_fasta(slurp(fasta)), uniq, names);
+        const std::vector<rkh::Fasta> records = rkh::read_fasta(slurp(fasta));
+        rkh::dedup_reads(records, uniq, names);
         const size_t n = uniq.size();
         std::string seq;
         std::vector<uint64_t> off(n + 1, 0);
@@ -121,6 +125,14 @@ int main(int argc, char **argv) {
         std::ofstream of(out, std::ios::binary);
         if (!of) throw std::runtime_error("cannot write " + out);
         of << rkh::jplace_document(tree, pl, call, guppy);
+        {   // notplaced_<query>.tsv under logs/ next to the output, as the reference's workdir/logs (Main_PLACEMENT_v07.java:208-214)
+            namespace fs = std::filesystem;
+            const fs::path dir = logs_given ? fs::path(logs) : fs::absolute(fs::path(out)).parent_path() / "logs";
+            fs::create_directories(dir);
+            std::ofstream nf(dir / ("notplaced_" + fs::path(fasta).filename().string() + ".tsv"), std::ios::binary);
+            if (!nf) throw std::runtime_error("cannot write the notplaced log under " + dir.string());
+            nf << rkh::notplaced_log(records, uniq, flags.data());
+        }
         std::cerr << n << " unique reads, " << pl.size() << " placed -> " << out << "\n";
         return 0;
     } catch (const std::exception &e) {

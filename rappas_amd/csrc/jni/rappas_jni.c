@@ -2,8 +2,9 @@
  * rappas_jni.c -- thin JNI adapter over the C ABI of include/rappas_place.h.
  *
  * Java side: class core.algos.NativePlacement.  This file is compiled only when a JDK is
- * available (JAVA_HOME set): this image has no JVM and no jni.h, so it is written blind and is NOT part of
- * build()/tests.  Build:
+ * available (JAVA_HOME set): this image has no JVM and no jni.h, so it is NOT part of build()/tests and has never run
+ * (UNTESTED; only syntax-checked with gcc -fsyntax-only against a throwaway declaration of the JNI entry points it uses).
+ * Build:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *       rappas_amd/csrc/jni/rappas_jni.c -Lrappas_amd -lrappas_place -o librappas_jni.so
  */
@@ -14,12 +15,23 @@
 #include <string.h>
 #include "rappas_place.h"
 
+static void throw_new(JNIEnv *env, const char *cls, const char *msg) {
+    jclass ex = (*env)->FindClass(env, cls);
+    if (ex) (*env)->ThrowNew(env, ex, msg);
+}
+#define THROW_ARG(msg) throw_new(env, "java/lang/IllegalArgumentException", msg)
+#define THROW_OOM(msg) throw_new(env, "java/lang/OutOfMemoryError", msg)
+
 static void throw_rk(JNIEnv *env, const char *where) {
     char msg[640];
     snprintf(msg, sizeof msg, "%s: %s", where, rk_last_error());
     jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
     if (ex) (*env)->ThrowNew(env, ex, msg);
 }
+
+/* Every array length is checked against the counts the engine will trust BEFORE any native pointer is taken: a wrong-sized
+ * Java array must become an IllegalArgumentException, never a native heap overwrite.  Get*ArrayElements results are
+ * NULL-checked (the JVM has then already raised OutOfMemoryError). */
 
 /* long dbCreate(int alphabet, boolean convertUO, int k, int nBranches, float thrLog10, float thr,
  *               long[] keyCodes, long[] rowOffsets, char[] branchIds, float[] scores, int device)
@@ -29,25 +41,91 @@ JNIEXPORT jlong JNICALL Java_core_algos_NativePlacement_dbCreate(JNIEnv *env, jc
         jboolean convertUO, jint k, jint nBranches, jfloat thrLog10, jfloat thr, jlongArray keyCodes,
         jlongArray rowOffsets, jcharArray branchIds, jfloatArray scores, jint device) {
     (void)cls;
+    if (!keyCodes || !rowOffsets || !branchIds || !scores) { THROW_ARG("dbCreate: null array"); return 0; }
+    if (k < 0 || nBranches < 0) { THROW_ARG("dbCreate: negative k / nBranches"); return 0; }
+    const jsize nKeys = (*env)->GetArrayLength(env, keyCodes);
+    const jsize nEnt = (*env)->GetArrayLength(env, branchIds);
+    if ((*env)->GetArrayLength(env, rowOffsets) != nKeys + 1) { THROW_ARG("dbCreate: rowOffsets must have keyCodes.length + 1 elements"); return 0; }
+    if ((*env)->GetArrayLength(env, scores) != nEnt) { THROW_ARG("dbCreate: branchIds and scores differ in length"); return 0; }
     rk_db_desc d;
+    memset(&d, 0, sizeof d);
     d.alphabet = (uint32_t)alphabet; d.convert_uo = convertUO ? 1u : 0u; d.k = (uint32_t)k;
     d.n_branches = (uint32_t)nBranches; d.thr_log10 = thrLog10; d.thr = thr;
-    d.n_keys = (uint64_t)(*env)->GetArrayLength(env, keyCodes);
+    d.n_keys = (uint64_t)nKeys;
     d.device = device; d.table_mode = RK_TABLE_AUTO;
     jlong *kc = (*env)->GetLongArrayElements(env, keyCodes, NULL);
-    jlong *ro = (*env)->GetLongArrayElements(env, rowOffsets, NULL);
-    jchar *br = (*env)->GetCharArrayElements(env, branchIds, NULL);   /* jchar == uint16: (char)nodeId */
-    jfloat *sc = (*env)->GetFloatArrayElements(env, scores, NULL);
-    d.key_codes = (const uint64_t *)kc; d.row_offsets = (const uint64_t *)ro;
-    d.branch_ids = (const uint16_t *)br; d.scores = sc;
+    jlong *ro = kc ? (*env)->GetLongArrayElements(env, rowOffsets, NULL) : NULL;
+    jchar *br = ro ? (*env)->GetCharArrayElements(env, branchIds, NULL) : NULL;   /* jchar == uint16: (char)nodeId */
+    jfloat *sc = br ? (*env)->GetFloatArrayElements(env, scores, NULL) : NULL;
     rk_db *db = NULL;
-    int rc = rk_db_create(&d, &db);
-    (*env)->ReleaseLongArrayElements(env, keyCodes, kc, JNI_ABORT);
-    (*env)->ReleaseLongArrayElements(env, rowOffsets, ro, JNI_ABORT);
-    (*env)->ReleaseCharArrayElements(env, branchIds, br, JNI_ABORT);
-    (*env)->ReleaseFloatArrayElements(env, scores, sc, JNI_ABORT);
+    int rc = RK_ERR_NOMEM;
+    int bad_offsets = 0;
+    if (sc) {
+        /* the CSR must end exactly at the entry arrays' length: rk_db_create reads branchIds / scores up to rowOffsets[nKeys] */
+        bad_offsets = (ro[0] != 0 || (uint64_t)ro[nKeys] != (uint64_t)nEnt);
+        if (!bad_offsets) {
+            d.key_codes = (const uint64_t *)kc; d.row_offsets = (const uint64_t *)ro;
+            d.branch_ids = (const uint16_t *)br; d.scores = sc;
+            rc = rk_db_create(&d, &db);
+        }
+    }
+    if (sc) (*env)->ReleaseFloatArrayElements(env, scores, sc, JNI_ABORT);
+    if (br) (*env)->ReleaseCharArrayElements(env, branchIds, br, JNI_ABORT);
+    if (ro) (*env)->ReleaseLongArrayElements(env, rowOffsets, ro, JNI_ABORT);
+    if (kc) (*env)->ReleaseLongArrayElements(env, keyCodes, kc, JNI_ABORT);
+    if (!sc) { if (!(*env)->ExceptionCheck(env)) THROW_OOM("dbCreate: could not pin the arrays"); return 0; }
+    if (bad_offsets) { THROW_ARG("dbCreate: rowOffsets must start at 0 and end at branchIds.length"); return 0; }
     if (rc != RK_OK) { throw_rk(env, "rk_db_create"); return 0; }
     return (jlong)(intptr_t)db;
+}
+
+/* shared by placeBatch / placeBatchMulti: length checks, pinning, the call, release */
+static void place_common(JNIEnv *env, rk_db *const *handles, uint32_t n_handles, jbyteArray seqs, jlongArray offs, jint keepAtMost,
+                         jfloat keepFactor, jint ambMode, jfloat nsBound, jbyteArray nRows, jcharArray branch, jfloatArray score,
+                         jdoubleArray lwr, jintArray flags) {
+    if (!seqs || !offs || !nRows || !branch || !score || !lwr || !flags) { THROW_ARG("placeBatch: null array"); return; }
+    if (keepAtMost < 1 || keepAtMost > 16) { THROW_ARG("placeBatch: keepAtMost outside 1..16"); return; }
+    const jsize nOff = (*env)->GetArrayLength(env, offs);
+    if (nOff < 1) { THROW_ARG("placeBatch: offs needs n + 1 >= 1 elements"); return; }
+    const jsize n = nOff - 1;
+    const jlong rows = (jlong)n * (jlong)keepAtMost;
+    if ((*env)->GetArrayLength(env, nRows) < n || (*env)->GetArrayLength(env, flags) < n ||
+        (jlong)(*env)->GetArrayLength(env, branch) < rows || (jlong)(*env)->GetArrayLength(env, score) < rows ||
+        (jlong)(*env)->GetArrayLength(env, lwr) < rows) {
+        THROW_ARG("placeBatch: result arrays need n (nRows, flags) and n * keepAtMost (branch, score, lwr) elements");
+        return;
+    }
+    const jsize nSeq = (*env)->GetArrayLength(env, seqs);
+    rk_params p = {(uint32_t)keepAtMost, keepFactor, (uint32_t)ambMode, nsBound};
+    jbyte *s = (*env)->GetByteArrayElements(env, seqs, NULL);
+    jlong *o = s ? (*env)->GetLongArrayElements(env, offs, NULL) : NULL;
+    jbyte *nr = o ? (*env)->GetByteArrayElements(env, nRows, NULL) : NULL;
+    jchar *b = nr ? (*env)->GetCharArrayElements(env, branch, NULL) : NULL;
+    jfloat *sc = b ? (*env)->GetFloatArrayElements(env, score, NULL) : NULL;
+    jdouble *w = sc ? (*env)->GetDoubleArrayElements(env, lwr, NULL) : NULL;
+    jint *f = w ? (*env)->GetIntArrayElements(env, flags, NULL) : NULL;
+    int rc = RK_ERR_NOMEM, bad_offsets = 0;
+    if (f) {
+        /* offsets must be monotone and stay inside seqs: the engine reads seqs[offs[i] .. offs[i+1]) */
+        bad_offsets = o[0] < 0 || o[n] > (jlong)nSeq;
+        for (jsize i = 0; i < n && !bad_offsets; i++) bad_offsets = o[i + 1] < o[i];
+        if (!bad_offsets) {
+            rk_result out = {(uint8_t *)nr, (uint16_t *)b, sc, w, (uint32_t *)f};
+            rc = n_handles == 1 ? rk_place_batch(handles[0], &p, (uint64_t)n, (const uint8_t *)s, (const uint64_t *)o, &out, NULL)
+                                : rk_place_batch_multi(handles, n_handles, &p, (uint64_t)n, (const uint8_t *)s, (const uint64_t *)o, &out, NULL);
+        }
+    }
+    const jint mode = (f && !bad_offsets && rc == RK_OK) ? 0 : JNI_ABORT;  /* copy results back only when there are results */
+    if (f) (*env)->ReleaseIntArrayElements(env, flags, f, mode);
+    if (w) (*env)->ReleaseDoubleArrayElements(env, lwr, w, mode);
+    if (sc) (*env)->ReleaseFloatArrayElements(env, score, sc, mode);
+    if (b) (*env)->ReleaseCharArrayElements(env, branch, b, mode);
+    if (nr) (*env)->ReleaseByteArrayElements(env, nRows, nr, mode);
+    if (o) (*env)->ReleaseLongArrayElements(env, offs, o, JNI_ABORT);
+    if (s) (*env)->ReleaseByteArrayElements(env, seqs, s, JNI_ABORT);
+    if (!f) { if (!(*env)->ExceptionCheck(env)) THROW_OOM("placeBatch: could not pin the arrays"); return; }
+    if (bad_offsets) { THROW_ARG("placeBatch: offs must be non-decreasing, start >= 0 and end <= seqs.length"); return; }
+    if (rc != RK_OK) throw_rk(env, n_handles == 1 ? "rk_place_batch" : "rk_place_batch_multi");
 }
 
 /* void placeBatch(long db, byte[] seqs, long[] offs, int keepAtMost, float keepFactor, int ambMode, float nsBound,
@@ -56,25 +134,9 @@ JNIEXPORT void JNICALL Java_core_algos_NativePlacement_placeBatch(JNIEnv *env, j
         jlongArray offs, jint keepAtMost, jfloat keepFactor, jint ambMode, jfloat nsBound, jbyteArray nRows,
         jcharArray branch, jfloatArray score, jdoubleArray lwr, jintArray flags) {
     (void)cls;
-    rk_params p = {(uint32_t)keepAtMost, keepFactor, (uint32_t)ambMode, nsBound};
-    const uint64_t n = (uint64_t)(*env)->GetArrayLength(env, offs) - 1;
-    jbyte *s = (*env)->GetByteArrayElements(env, seqs, NULL);
-    jlong *o = (*env)->GetLongArrayElements(env, offs, NULL);
-    jbyte *nr = (*env)->GetByteArrayElements(env, nRows, NULL);
-    jchar *b = (*env)->GetCharArrayElements(env, branch, NULL);
-    jfloat *sc = (*env)->GetFloatArrayElements(env, score, NULL);
-    jdouble *w = (*env)->GetDoubleArrayElements(env, lwr, NULL);
-    jint *f = (*env)->GetIntArrayElements(env, flags, NULL);
-    rk_result out = {(uint8_t *)nr, (uint16_t *)b, sc, w, (uint32_t *)f};
-    int rc = rk_place_batch((rk_db *)(intptr_t)db, &p, n, (const uint8_t *)s, (const uint64_t *)o, &out, NULL);
-    (*env)->ReleaseByteArrayElements(env, seqs, s, JNI_ABORT);
-    (*env)->ReleaseLongArrayElements(env, offs, o, JNI_ABORT);
-    (*env)->ReleaseByteArrayElements(env, nRows, nr, 0);
-    (*env)->ReleaseCharArrayElements(env, branch, b, 0);
-    (*env)->ReleaseFloatArrayElements(env, score, sc, 0);
-    (*env)->ReleaseDoubleArrayElements(env, lwr, w, 0);
-    (*env)->ReleaseIntArrayElements(env, flags, f, 0);
-    if (rc != RK_OK) throw_rk(env, "rk_place_batch");
+    rk_db *h = (rk_db *)(intptr_t)db;
+    if (!h) { THROW_ARG("placeBatch: null database handle"); return; }
+    place_common(env, &h, 1, seqs, offs, keepAtMost, keepFactor, ambMode, nsBound, nRows, branch, score, lwr, flags);
 }
 
 JNIEXPORT void JNICALL Java_core_algos_NativePlacement_dbDestroy(JNIEnv *env, jclass cls, jlong db) {
@@ -91,6 +153,15 @@ JNIEXPORT jobjectArray JNICALL Java_core_algos_NativePlacement_buildDb(JNIEnv *e
         jint nSites, jint nStates, jbyteArray states, jfloatArray ppLog10, jcharArray nodeBranch, jfloat thrLog10,
         jboolean gapJumps, jboolean limitTo1Jump, jintArray gapOff, jintArray gapLen, jint device) {
     (void)cls;
+    if (!states || !ppLog10 || !nodeBranch || (gapJumps && (!gapOff || !gapLen))) { THROW_ARG("buildDb: null array"); return NULL; }
+    if (nNodes < 0 || nSites < 1 || nStates < 1 || k < 0) { THROW_ARG("buildDb: negative or zero dimension"); return NULL; }
+    const jlong cells = (jlong)nNodes * (jlong)nSites * (jlong)nStates;
+    if ((jlong)(*env)->GetArrayLength(env, states) != cells || (jlong)(*env)->GetArrayLength(env, ppLog10) != cells ||
+        (*env)->GetArrayLength(env, nodeBranch) != nNodes) {
+        THROW_ARG("buildDb: states / ppLog10 need nNodes * nSites * nStates elements, nodeBranch nNodes");
+        return NULL;
+    }
+    if (gapJumps && (*env)->GetArrayLength(env, gapOff) != nSites + 1) { THROW_ARG("buildDb: gapOff needs nSites + 1 elements"); return NULL; }
     rk_build_desc d;
     rk_built_db b;
     memset(&d, 0, sizeof d);
@@ -98,23 +169,31 @@ JNIEXPORT jobjectArray JNICALL Java_core_algos_NativePlacement_buildDb(JNIEnv *e
     d.n_states = (uint32_t)nStates; d.do_gap_jumps = gapJumps ? 1u : 0u; d.limit_to_1_jump = limitTo1Jump ? 1u : 0u;
     d.thr_log10 = thrLog10; d.device = device;
     jbyte *st = (*env)->GetByteArrayElements(env, states, NULL);
-    jfloat *pp = (*env)->GetFloatArrayElements(env, ppLog10, NULL);
-    jchar *nb = (*env)->GetCharArrayElements(env, nodeBranch, NULL);
-    jint *go = gapJumps ? (*env)->GetIntArrayElements(env, gapOff, NULL) : NULL;
-    jint *gl = gapJumps ? (*env)->GetIntArrayElements(env, gapLen, NULL) : NULL;
-    d.states = (const uint8_t *)st; d.pp_log10 = pp; d.node_branch = (const uint16_t *)nb;
-    d.gap_off = (const uint32_t *)go; d.gap_len = (const int32_t *)gl;
-    int rc = rk_build_db(&d, &b);
-    (*env)->ReleaseByteArrayElements(env, states, st, JNI_ABORT);
-    (*env)->ReleaseFloatArrayElements(env, ppLog10, pp, JNI_ABORT);
-    (*env)->ReleaseCharArrayElements(env, nodeBranch, nb, JNI_ABORT);
-    if (go) (*env)->ReleaseIntArrayElements(env, gapOff, go, JNI_ABORT);
+    jfloat *pp = st ? (*env)->GetFloatArrayElements(env, ppLog10, NULL) : NULL;
+    jchar *nb = pp ? (*env)->GetCharArrayElements(env, nodeBranch, NULL) : NULL;
+    jint *go = (nb && gapJumps) ? (*env)->GetIntArrayElements(env, gapOff, NULL) : NULL;
+    jint *gl = (go && gapJumps) ? (*env)->GetIntArrayElements(env, gapLen, NULL) : NULL;
+    const int pinned = nb && (!gapJumps || (go && gl));
+    int rc = RK_ERR_NOMEM, bad_gaps = 0;
+    if (pinned) {
+        if (gapJumps) bad_gaps = go[0] != 0 || go[nSites] < 0 || go[nSites] != (*env)->GetArrayLength(env, gapLen);
+        if (!bad_gaps) {
+            d.states = (const uint8_t *)st; d.pp_log10 = pp; d.node_branch = (const uint16_t *)nb;
+            d.gap_off = (const uint32_t *)go; d.gap_len = (const int32_t *)gl;
+            rc = rk_build_db(&d, &b);
+        }
+    }
     if (gl) (*env)->ReleaseIntArrayElements(env, gapLen, gl, JNI_ABORT);
+    if (go) (*env)->ReleaseIntArrayElements(env, gapOff, go, JNI_ABORT);
+    if (nb) (*env)->ReleaseCharArrayElements(env, nodeBranch, nb, JNI_ABORT);
+    if (pp) (*env)->ReleaseFloatArrayElements(env, ppLog10, pp, JNI_ABORT);
+    if (st) (*env)->ReleaseByteArrayElements(env, states, st, JNI_ABORT);
+    if (!pinned) { if (!(*env)->ExceptionCheck(env)) THROW_OOM("buildDb: could not pin the arrays"); return NULL; }
+    if (bad_gaps) { THROW_ARG("buildDb: gapOff must start at 0 and end at gapLen.length"); return NULL; }
     if (rc != RK_OK) { throw_rk(env, "rk_build_db"); return NULL; }
     jobjectArray res = NULL;
     if (b.n_entries > 0x7FFFFFF0ull || b.n_keys > 0x7FFFFFF0ull) {
-        jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
-        if (ex) (*env)->ThrowNew(env, ex, "rk_build_db: result does not fit Java arrays; build per node batch");
+        throw_new(env, "java/lang/RuntimeException", "rk_build_db: result does not fit Java arrays; build per node batch");
     } else {
         jlongArray kc = (*env)->NewLongArray(env, (jsize)b.n_keys);
         jlongArray ro = (*env)->NewLongArray(env, (jsize)b.n_keys + 1);
@@ -143,33 +222,15 @@ JNIEXPORT void JNICALL Java_core_algos_NativePlacement_placeBatchMulti(JNIEnv *e
         jlongArray offs, jint keepAtMost, jfloat keepFactor, jint ambMode, jfloat nsBound, jbyteArray nRows,
         jcharArray branch, jfloatArray score, jdoubleArray lwr, jintArray flags) {
     (void)cls;
-    rk_params p = {(uint32_t)keepAtMost, keepFactor, (uint32_t)ambMode, nsBound};
-    const uint64_t n = (uint64_t)(*env)->GetArrayLength(env, offs) - 1;
+    if (!dbs) { THROW_ARG("placeBatchMulti: null handle array"); return; }
     const jsize nd = (*env)->GetArrayLength(env, dbs);
     rk_db *handles[64];
-    if (nd < 1 || nd > 64) {
-        jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
-        if (ex) (*env)->ThrowNew(env, ex, "placeBatchMulti: 1..64 database handles");
-        return;
-    }
+    if (nd < 1 || nd > 64) { THROW_ARG("placeBatchMulti: 1..64 database handles"); return; }
     jlong *h = (*env)->GetLongArrayElements(env, dbs, NULL);
-    for (jsize g = 0; g < nd; g++) handles[g] = (rk_db *)(intptr_t)h[g];
+    if (!h) { if (!(*env)->ExceptionCheck(env)) THROW_OOM("placeBatchMulti: could not pin the handle array"); return; }
+    int null_handle = 0;
+    for (jsize g = 0; g < nd; g++) { handles[g] = (rk_db *)(intptr_t)h[g]; null_handle |= handles[g] == NULL; }
     (*env)->ReleaseLongArrayElements(env, dbs, h, JNI_ABORT);
-    jbyte *s = (*env)->GetByteArrayElements(env, seqs, NULL);
-    jlong *o = (*env)->GetLongArrayElements(env, offs, NULL);
-    jbyte *nr = (*env)->GetByteArrayElements(env, nRows, NULL);
-    jchar *b = (*env)->GetCharArrayElements(env, branch, NULL);
-    jfloat *sc = (*env)->GetFloatArrayElements(env, score, NULL);
-    jdouble *w = (*env)->GetDoubleArrayElements(env, lwr, NULL);
-    jint *f = (*env)->GetIntArrayElements(env, flags, NULL);
-    rk_result out = {(uint8_t *)nr, (uint16_t *)b, sc, w, (uint32_t *)f};
-    int rc = rk_place_batch_multi(handles, (uint32_t)nd, &p, n, (const uint8_t *)s, (const uint64_t *)o, &out, NULL);
-    (*env)->ReleaseByteArrayElements(env, seqs, s, JNI_ABORT);
-    (*env)->ReleaseLongArrayElements(env, offs, o, JNI_ABORT);
-    (*env)->ReleaseByteArrayElements(env, nRows, nr, 0);
-    (*env)->ReleaseCharArrayElements(env, branch, b, 0);
-    (*env)->ReleaseFloatArrayElements(env, score, sc, 0);
-    (*env)->ReleaseDoubleArrayElements(env, lwr, w, 0);
-    (*env)->ReleaseIntArrayElements(env, flags, f, 0);
-    if (rc != RK_OK) throw_rk(env, "rk_place_batch_multi");
+    if (null_handle) { THROW_ARG("placeBatchMulti: null database handle"); return; }
+    place_common(env, handles, (uint32_t)nd, seqs, offs, keepAtMost, keepFactor, ambMode, nsBound, nRows, branch, score, lwr, flags);
 }

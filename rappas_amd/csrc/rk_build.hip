@@ -12,7 +12,8 @@
 // codes -> CSR.
 // No CPU fallback: without a HIP device rk_build_db fails with RK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -520,9 +521,20 @@ extern "C" void rk_built_free(rk_built_db *b) {
     memset(b, 0, sizeof(*b));
 }
 
+static int build_db_impl(const rk_build_desc *d, rk_built_db *out);
+
 extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     if (!d || !out) return fail_msg(RK_ERR_INVALID, "rk_build_db: null argument");
     memset(out, 0, sizeof(*out));
+    int prev = -1;
+    (void)hipGetDevice(&prev);  // the caller's current device is put back whatever happens below
+    const int rc = build_db_impl(d, out);
+    if (rc != RK_OK) rk_built_free(out);  // nothing half-built is handed back
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+
+static int build_db_impl(const rk_build_desc *d, rk_built_db *out) {
     if (d->alphabet != RK_ALPHABET_DNA && d->alphabet != RK_ALPHABET_AA)
         return fail_msg(RK_ERR_INVALID, "rk_build_db: alphabet must be 4 (DNA) or 20 (AA), got %u", d->alphabet);
     const u32 bits = d->alphabet == RK_ALPHABET_DNA ? 2 : 5;
@@ -548,7 +560,9 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
             if (d->gap_off[i + 1] < d->gap_off[i]) return fail_msg(RK_ERR_INVALID, "rk_build_db: gap_off not monotone at site %u", i);
         n_gap = d->gap_off[d->n_sites];
         for (size_t g = 0; g < n_gap; g++)
-            if (d->gap_len[g] < 1) return fail_msg(RK_ERR_INVALID, "rk_build_db: gap interval %zu has length %d", g, d->gap_len[g]);
+            // (an interval longer than the alignment cannot come out of Alignment.getGapIntervals; the kernel adds it to a site index)
+            if (d->gap_len[g] < 1 || (u32)d->gap_len[g] > d->n_sites)
+                return fail_msg(RK_ERR_INVALID, "rk_build_db: gap interval %zu has length %d (alignment has %u sites)", g, d->gap_len[g], d->n_sites);
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -590,7 +604,7 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     struct EvGuard { hipEvent_t a, b, c; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evg{e0, e1, e2};
 
     // ---- node batches: explore -> sort -> max per key, folded into the running set of unique (key, best score) pairs ----
-    // (one batch unless the tuple buffer of a single launch would pass ~2.7e8 slots: hipCUB counts items in 32 bits)
+    // (one batch unless the tuple buffer of a single launch would pass ~2.7e8 slots: the sort is handed 32-bit item counts)
     const unsigned blocks = (unsigned)prop.multiProcessorCount * 3;  // persistent: 12 waves per CU (LDS: 10.5 KB per wave)
     const u64 chunk_slack = (u64)blocks * BUILD_WAVES_PER_BLOCK * TUPLE_CHUNK;  // every wave may leave one chunk half empty
     // slots one batch may fill: bounded by the 32-bit item counts of the sort and by device memory (12 bytes per slot, twice for
@@ -682,20 +696,23 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
             const int n = (int)(n_tuples + run_n);  // real pairs: the first n of the sorted slots
             DevBuf b_keys2, b_scores2, b_tmp, b_nruns;
             if ((rc = b_keys2.alloc((size_t)n_sort * 8)) || (rc = b_scores2.alloc((size_t)n_sort * 4)) || (rc = b_nruns.alloc(8))) return rc;
-            hipcub::DoubleBuffer<u64> kb(b_keys.as<u64>(), b_keys2.as<u64>());
-            hipcub::DoubleBuffer<float> vb(b_scores.as<float>(), b_scores2.as<float>());
+            // rocPRIM called natively (ROCm's own device primitives, no CUB-compatibility layer in between)
+            rocprim::double_buffer<u64> kb(b_keys.as<u64>(), b_keys2.as<u64>());
+            rocprim::double_buffer<float> vb(b_scores.as<float>(), b_scores2.as<float>());
             size_t tmp_bytes = 0;
-            RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, vb, n_sort, 0, end_bit));
+            RK_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n_sort, 0u, (unsigned)end_bit, (hipStream_t)0));
             if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
-            RK_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, kb, vb, n_sort, 0, end_bit));
-            u64 *sorted_k = kb.Current();
-            float *sorted_v = vb.Current();
-            u64 *uniq_k = kb.Alternate();
-            float *max_v = vb.Alternate();
+            RK_HIP_TRY(rocprim::radix_sort_pairs(b_tmp.p, tmp_bytes, kb, vb, (size_t)n_sort, 0u, (unsigned)end_bit, (hipStream_t)0));
+            u64 *sorted_k = kb.current();
+            float *sorted_v = vb.current();
+            u64 *uniq_k = kb.alternate();
+            float *max_v = vb.alternate();
             tmp_bytes = 0;
-            RK_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_bytes, sorted_k, uniq_k, sorted_v, max_v, b_nruns.as<int>(), hipcub::Max(), n));
+            RK_HIP_TRY(rocprim::reduce_by_key(nullptr, tmp_bytes, sorted_k, sorted_v, (size_t)n, uniq_k, max_v, b_nruns.as<int>(),
+                                              rocprim::maximum<float>(), rocprim::equal_to<u64>(), (hipStream_t)0));
             if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
-            RK_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(b_tmp.p, tmp_bytes, sorted_k, uniq_k, sorted_v, max_v, b_nruns.as<int>(), hipcub::Max(), n));
+            RK_HIP_TRY(rocprim::reduce_by_key(b_tmp.p, tmp_bytes, sorted_k, sorted_v, (size_t)n, uniq_k, max_v, b_nruns.as<int>(),
+                                              rocprim::maximum<float>(), rocprim::equal_to<u64>(), (hipStream_t)0));
             int runs = 0;
             RK_HIP_TRY(hipMemcpy(&runs, b_nruns.p, 4, hipMemcpyDeviceToHost));
             if ((rc = run_keys.alloc((size_t)runs * 8)) || (rc = run_vals.alloc((size_t)runs * 4))) return rc;
@@ -734,12 +751,12 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
         const int runs = (int)run_n;
         DevBuf b_tmp, b_nruns, b_codes, b_counts, b_branch;
         if ((rc = b_codes.alloc((size_t)runs * 8)) || (rc = b_counts.alloc((size_t)runs * 4)) || (rc = b_nruns.alloc(8)) ||
-            (rc = b_branch.alloc((size_t)runs * 2))) { rk_built_free(out); return rc; }
-        hipcub::TransformInputIterator<u64, ShiftRight16, u64 *> code_it(run_keys.as<u64>(), ShiftRight16());
+            (rc = b_branch.alloc((size_t)runs * 2))) return rc;
+        auto code_it = rocprim::make_transform_iterator(run_keys.as<u64>(), ShiftRight16());
         size_t tmp_bytes = 0;
-        RK_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_bytes, code_it, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), runs));
-        if ((rc = b_tmp.alloc(tmp_bytes))) { rk_built_free(out); return rc; }
-        RK_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(b_tmp.p, tmp_bytes, code_it, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), runs));
+        RK_HIP_TRY(rocprim::run_length_encode(nullptr, tmp_bytes, code_it, (unsigned)runs, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), (hipStream_t)0));
+        if ((rc = b_tmp.alloc(tmp_bytes))) return rc;
+        RK_HIP_TRY(rocprim::run_length_encode(b_tmp.p, tmp_bytes, code_it, (unsigned)runs, b_codes.as<u64>(), b_counts.as<int>(), b_nruns.as<int>(), (hipStream_t)0));
         hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)prop.multiProcessorCount * 8), dim3(256), 0, 0, run_keys.as<u64>(), run_n, b_branch.as<unsigned short>());
         RK_HIP_TRY(hipGetLastError());
         int nk = 0;

@@ -646,25 +646,59 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
     std::vector<int> codes(n_dbs, RK_OK);
     std::vector<std::string> msgs(n_dbs);
     std::vector<rk_counters> cts(n_dbs);
-    std::vector<std::thread> workers;
-    for (uint32_t g = 0; g < n_dbs; g++) {
+    // developer / test knob: the first attempt of this shard reports a device failure (exercises the re-queue below)
+    const int inject = getenv("RK_TEST_FAIL_SHARD") ? atoi(getenv("RK_TEST_FAIL_SHARD")) : -1;
+    auto run_shard = [&](uint32_t g, uint32_t on, bool first_attempt) {  // shard g of the batch on handle `on`, in the calling thread
         const uint64_t lo = n_reads * g / n_dbs, hi = n_reads * (g + 1) / n_dbs;
-        workers.emplace_back([&, g, lo, hi]() {
-            cts[g] = rk_counters{};
-            if (hi == lo) return;
-            rk_result r{out->n_rows + lo, out->branch + lo * K, out->score + lo * K, out->lwr + lo * K, out->flags + lo};
-            codes[g] = rk_place_batch(dbs[g], p, hi - lo, seq_ascii, seq_off + lo, &r, &cts[g]);
-            if (codes[g] != RK_OK) msgs[g] = rk_last_error();  // the message lives in this thread: hand it over
-        });
+        cts[g] = rk_counters{};
+        codes[g] = RK_OK;
+        if (hi == lo) return;
+        if (first_attempt && inject == (int)g) {
+            codes[g] = RK_ERR_HIP;
+            msgs[g] = "injected failure (RK_TEST_FAIL_SHARD)";
+            return;
+        }
+        rk_result r{out->n_rows + lo, out->branch + lo * K, out->score + lo * K, out->lwr + lo * K, out->flags + lo};
+        codes[g] = rk_place_batch(dbs[on], p, hi - lo, seq_ascii, seq_off + lo, &r, &cts[g]);
+        if (codes[g] != RK_OK) msgs[g] = rk_last_error();  // the message lives in this thread: hand it over
+    };
+    {
+        std::vector<std::thread> workers;
+        for (uint32_t g = 0; g < n_dbs; g++) workers.emplace_back([&, g]() { run_shard(g, g, true); });
+        for (std::thread &t : workers) t.join();
     }
-    for (std::thread &t : workers) t.join();
+    // A shard whose device failed (per-GPU failure => shard re-queued on another GPU) is placed again on
+    // the handles that did finish, one after the other, each attempt in a fresh host thread; the process is never restarted.
+    // Argument errors (RK_ERR_INVALID / RK_ERR_UNSUPPORTED) would fail anywhere and are not retried.
+    std::vector<char> healthy(n_dbs);
+    for (uint32_t g = 0; g < n_dbs; g++) healthy[g] = codes[g] == RK_OK;
+    std::string note;
+    for (uint32_t g = 0; g < n_dbs; g++) {
+        if (codes[g] == RK_OK || codes[g] == RK_ERR_INVALID || codes[g] == RK_ERR_UNSUPPORTED) continue;
+        const std::string first_msg = msgs[g];
+        const int first_code = codes[g];
+        for (uint32_t h = 0; h < n_dbs && codes[g] != RK_OK; h++) {
+            if (!healthy[h]) continue;
+            std::thread t([&, g, h]() { run_shard(g, h, false); });
+            t.join();
+            if (codes[g] == RK_OK) {
+                char buf[256];
+                snprintf(buf, sizeof(buf), "shard %u failed on device %d (%d: %.120s) and was placed on device %d; ", g, dbs[g]->info.device,
+                         first_code, first_msg.c_str(), dbs[h]->info.device);
+                note += buf;
+            }
+        }
+        if (codes[g] != RK_OK) { codes[g] = first_code; msgs[g] = first_msg; }
+    }
     rk_counters total{};
     for (uint32_t g = 0; g < n_dbs; g++) {
-        if (codes[g] != RK_OK) return fail(codes[g], "rk_place_batch_multi: shard %u: %s", g, msgs[g].c_str());
+        if (codes[g] != RK_OK) return fail(codes[g], "rk_place_batch_multi: shard %u (device %d): %s", g, dbs[g]->info.device, msgs[g].c_str());
         total.reads += cts[g].reads; total.placed += cts[g].placed; total.unplaced += cts[g].unplaced;
         total.bad_char += cts[g].bad_char; total.too_short += cts[g].too_short; total.ambiguous += cts[g].ambiguous;
     }
     if (counters) *counters = total;
+    // success, but the caller can still learn which device dropped out: rk_last_error() carries the note (empty otherwise)
+    (void)fail(RK_OK, "%s", note.c_str());
     return RK_OK;
 }
 

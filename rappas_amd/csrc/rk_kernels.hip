@@ -1159,17 +1159,47 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
         auto emit_batch = [&](const u64 (&desc)[PU], bool more) {
             u32 nch[PU], excl[PU];
             int total = 0;
+            bool wide_rows = false;
 #pragma unroll
             for (int u = 0; u < PU; u++) {
                 const u32 lenp = (u32)desc[u] & DESC_LEN_MASK;
                 nch[u] = (lenp + G - 1) >> 4;
-                u32 incl = nch[u];
-                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);
-                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
-                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
-                incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
-                excl[u] = (u32)total + incl - nch[u];
-                total += (int)__shfl(incl, G - 1, G);
+                wide_rows = wide_rows || nch[u] > 15u;
+            }
+            auto row_scan = [](u32 v) {  // inclusive prefix sum over the 16 lanes of a DPP row (row_shr shifts zeros in)
+                v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+                v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+                v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+                v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+                return v;
+            };
+            if (!__any(wide_rows)) {
+                // rows of <= 15 units each (240 entries: nearly always): four sub-batches share one scan, one byte each
+                // (a byte's sum over the 16 lanes is <= 240, so nothing carries into its neighbour)
+#pragma unroll
+                for (int u0 = 0; u0 < PU; u0 += 4) {
+                    u32 packed = nch[u0];
+                    if (u0 + 1 < PU) packed |= nch[u0 + 1 < PU ? u0 + 1 : u0] << 8;
+                    if (u0 + 2 < PU) packed |= nch[u0 + 2 < PU ? u0 + 2 : u0] << 16;
+                    if (u0 + 3 < PU) packed |= nch[u0 + 3 < PU ? u0 + 3 : u0] << 24;
+                    const u32 incl = row_scan(packed);
+                    const u32 tot = row_bcast32<15>(incl);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if (u0 + b < PU) {
+                            const int u = u0 + b < PU ? u0 + b : u0;
+                            excl[u] = (u32)total + ((incl >> (8 * b)) & 0xFFu) - nch[u];
+                            total += (int)((tot >> (8 * b)) & 0xFFu);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const u32 incl = row_scan(nch[u]);
+                    excl[u] = (u32)total + incl - nch[u];
+                    total += (int)row_bcast32<15>(incl);
+                }
             }
             if (__any(more && cnt + total > cap_items)) flush();
             if (__any(more && total > cap_items)) {

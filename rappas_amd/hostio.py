@@ -65,6 +65,16 @@ def dedup_reads(records):
     return unique, names
 
 
+def notplaced_log(records, unique, placed):
+    """Text of `notplaced_<query>.tsv` (Main_PLACEMENT_v07.java:214, PlacementProcess.java:797-806): the FULL header of every
+    read none of whose k-mers is in the database, one per line, in file order.  The reference registers a checksum only for reads
+    that produce a jplace record (:1046), so every later copy of an unplaced read is placed again, fails again and is logged
+    again: all occurrences are listed, not just the first.  `placed[i]`: unique read i has RK_FLAG_PLACED."""
+    index = {hashlib.md5(seq.replace("-", "").encode()).digest(): i for i, (_, seq) in enumerate(unique)}
+    lines = [header for header, seq in records if not placed[index[hashlib.md5(seq.replace("-", "").encode()).digest()]]]
+    return "".join(h + "\n" for h in lines)
+
+
 def pack_batch(seqs):
     """list of str -> (uint8 concatenation, uint64 offsets) as rk_place_batch takes them."""
     off = np.zeros(len(seqs) + 1, np.uint64)

@@ -5,6 +5,7 @@ from the JSON dump `--jsondb` writes (src/main_v2/SessionNext_v2.java:214-270) i
 Only the placement itself runs on the GPU; ingest and the jplace writer are rappas_amd/hostio.py.
 """
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -20,7 +21,8 @@ def place_file(db_text, fasta_text, keep_at_most=7, keep_factor=0.01, amb="mean"
     db = PhyloKmerDB(d["alphabet"], d["k"], d["n_branches"], d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"],
                      d["branch_ids"], d["scores"], device=device)
     try:
-        unique, names = hostio.dedup_reads(hostio.read_fasta(fasta_text))
+        records = hostio.read_fasta(fasta_text)
+        unique, names = hostio.dedup_reads(records)
         seq, off = hostio.pack_batch([s for _, s in unique])
         res = PlacementProcess(db, ns_bound).processQueries(
             seq, off, keepAtMost=keep_at_most, keepFactor=keep_factor, treatAmbiguities=(amb != "skip"),
@@ -28,6 +30,7 @@ def place_file(db_text, fasta_text, keep_at_most=7, keep_factor=0.01, amb="mean"
     finally:
         db.close()
     pl = hostio.jplace_placements(tree, names, res.n_rows, res.branch, res.score, res.lwr, guppy)
+    res.notplaced = hostio.notplaced_log(records, unique, (res.flags & 1) != 0)
     return hostio.jplace_document(tree, pl, call_string, guppy), res
 
 
@@ -42,6 +45,7 @@ def main(argv=None):
     ap.add_argument("--nsbound", type=float, default=float("-inf"))
     ap.add_argument("--guppy-compat", action="store_true")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--logs", default=None, help="directory of notplaced_<query>.tsv (default: logs/ next to --out, like the reference's workdir/logs)")
     a = ap.parse_args(argv)
     with open(a.jsondb, "rb") as f:
         db_text = f.read()
@@ -52,6 +56,10 @@ def main(argv=None):
                           a.device)
     with open(a.out, "w") as f:
         f.write(doc)
+    logs = a.logs if a.logs is not None else os.path.join(os.path.dirname(os.path.abspath(a.out)), "logs")
+    os.makedirs(logs, exist_ok=True)
+    with open(os.path.join(logs, "notplaced_" + os.path.basename(a.fasta) + ".tsv"), "w") as f:
+        f.write(res.notplaced)
     placed = int(np.count_nonzero(res.n_rows))
     print(f"{len(res.n_rows)} unique reads, {placed} placed -> {a.out}", file=sys.stderr)
     return 0

@@ -113,3 +113,29 @@ def test_native_driver_writes_the_same_jplace(tmp_path, extra):
     assert r.returncode == 0, r.stderr
     cpp = (tmp_path / "out.jplace").read_bytes()
     assert cpp == py and len(py) > 10000
+    # both drivers also leave logs/notplaced_<query>.tsv (PlacementProcess.java:797-806), identical
+
+
+def test_notplaced_log_is_written_by_both_drivers(tmp_path):
+    import subprocess
+    from rappas_amd import build
+    exe = build.build_host_tools()
+    db = synth.make_db(4, 6, 75, 300, 2000, seed=13)  # few keys: short reads can miss every row
+    nwk = synth.make_newick(75, seed=6)
+    (tmp_path / "db.json").write_text(hostio.dump_jsondb(db, nwk))
+    seq, off = synth.make_reads(4, 400, 9, seed=3)
+    reads = [bytes(seq[int(off[i]):int(off[i + 1])]).decode() for i in range(400)]
+    fasta = "".join(f">r{i} note {i}\n{s}\n" for i, s in enumerate(reads))
+    (tmp_path / "q.fasta").write_text(fasta)
+    args = ["--jsondb", str(tmp_path / "db.json"), "--fasta", str(tmp_path / "q.fasta"), "--out", str(tmp_path / "out.jplace")]
+    assert place_tool.main(args) == 0
+    log = tmp_path / "logs" / "notplaced_q.fasta.tsv"
+    py = log.read_text()
+    odb = O.OracleDB.from_synth(db)
+    ref = odb.place(seq, off)
+    want = "".join(f"r{i} note {i}\n" for i in range(400) if not (ref["flags"][i] & 1))
+    assert py == want and 0 < py.count("\n") < 400
+    log.unlink()
+    r = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert log.read_text() == py

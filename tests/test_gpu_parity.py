@@ -505,3 +505,28 @@ def test_forced_passes_equal_the_single_pass_result(passes, monkeypatch):
     many, _, _ = run_case(sdb, odb, seq, off, "direct8", 0, "mean")
     assert np.array_equal(one.branch, many.branch) and np.array_equal(one.score.view(np.uint32), many.score.view(np.uint32))
     assert np.array_equal(one.n_rows, many.n_rows) and np.array_equal(one.lwr, many.lwr)
+
+
+def test_failed_shard_is_requeued_on_a_healthy_device(c2_small, monkeypatch):
+    """a per-GPU failure re-queues the shard on another GPU.  Shard 1 of 3 reports a device failure on its
+    first attempt (test knob); the call must still succeed, give the single-call results and name the device in rk_last_error."""
+    sdb, odb = c2_small
+    seq, off = synth.make_reads(4, 3001, 150, seed=8, amb_rate=0.001)
+    dbs = [ra.PhyloKmerDB.from_synth(sdb) for _ in range(3)]
+    try:
+        pp = ra.PlacementProcess(dbs[0])
+        want = pp.processQueries(seq, off)
+        monkeypatch.setenv("RK_TEST_FAIL_SHARD", "1")
+        got = pp.processQueriesMulti(dbs, seq, off)
+        note = _lib.load().rk_last_error().decode()
+        assert "shard 1 failed on device 0" in note and "injected" in note
+        for f in ("n_rows", "branch", "flags", "lwr"):
+            assert np.array_equal(getattr(got, f), getattr(want, f))
+        assert np.array_equal(got.score.view(np.uint32), want.score.view(np.uint32))
+        assert got.counters == want.counters
+        monkeypatch.delenv("RK_TEST_FAIL_SHARD")
+        pp.processQueriesMulti(dbs, seq, off)
+        assert _lib.load().rk_last_error().decode() == ""
+    finally:
+        for d in dbs:
+            d.close()

@@ -32,6 +32,17 @@ def test_dedup_rules():
     assert seq.size == 0 and off.tolist() == [0]
 
 
+def test_notplaced_log_lists_every_occurrence_with_its_full_header():
+    """PlacementProcess.java:797-806 + :1046: checksums are registered for placed reads only, so each copy of an unplaced read
+    is placed again and logged again, with the header as it stands in the file"""
+    rec = [("a first", "ACGT"), ("n1 some text", "NNNN"), ("b", "AC-GT"), ("n2", "NN-NN"), ("n3 x", "GGGG")]
+    uniq, names = hostio.dedup_reads(rec)
+    assert [h for h, _ in uniq] == ["a first", "n1 some text", "n3 x"]
+    placed = np.array([True, False, False])
+    assert hostio.notplaced_log(rec, uniq, placed) == "n1 some text\nn2\nn3 x\n"
+    assert hostio.notplaced_log(rec, uniq, np.array([True, True, True])) == ""
+
+
 def test_newick_ids_and_jplace_edges():
     t = hostio.parse_newick("((A:0.1,B:0.2)C:0.3,D:0.4)R;")
     assert [(n.id, n.label) for n in t.nodes] == [(0, "R"), (1, "C"), (2, "A"), (3, "B"), (4, "D")]
