@@ -89,3 +89,23 @@ def test_jsondb_parse(rk_place, tmp_path):
 
 def test_string_escaping_follows_json_simple():
     assert hostio._jstr('a/b"c\\d\n\x01\x7f é') == '"a\\/b\\"c\\\\d\\n\\u0001\\u007F\\u2028é"'
+
+
+def test_native_loader_reads_the_fixture_authored_from_the_java(rk_place):
+    """tests/golden/jsondb_toy.json (written by hand from SessionNext_v2.saveToJSON + json-simple, not by dump_jsondb):
+    the C++ loader gives the rows typed into the authoring script, in the dump's order"""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsondb_toy.json")
+    out = run(rk_place, "--load-jsondb", path).splitlines()
+    assert out[0] == "3 0.052734375 -1.2779074 7 13"
+    assert out[1] == "((A:0.100000000000,B:0.200000000000)C:0.300000000000,D:0.400000000000)R;"
+    code = lambda kmer: sum("ATCG".index(c) << (2 * i) for i, c in enumerate(kmer))
+    assert out[2:] == [
+        f"{code('ATC')} 1:-0.30103 2:-0.04575749",
+        f"{code('AAA')} 2:-1.0 4:-0.2218487",
+        f"{code('GCA')} 1:-0.75",
+        f"{code('TTT')} 1:-1.2779074 3:-0.0",
+        f"{code('TCG')} 2:-0.5 3:-1.25 4:-0.125",
+        f"{code('GAT')} 1:-1.2041199 3:-0.69897",
+        f"{code('CGA')} 4:-9.765625E-4",
+    ]

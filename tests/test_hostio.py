@@ -141,3 +141,54 @@ def test_jsondb_rejects_non_dna_kmers():
            '"hash":{"RH":{"1":-0.5}}}')
     with pytest.raises(ValueError, match="not a DNA"):
         hostio.load_jsondb(txt)
+
+
+# ---- the --jsondb fixture authored from the Java (tests/golden/make_jsondb_fixture.py), not from dump_jsondb ----
+def _fixture_text():
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return open(os.path.join(here, "jsondb_toy.json")).read()
+
+
+def test_jsondb_fixture_is_what_its_authoring_script_writes():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_jsondb_fixture.py")
+    spec = importlib.util.spec_from_file_location("make_jsondb_fixture", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.document() == _fixture_text()
+    # java.lang.String.hashCode known answers the HashMap order rests on
+    assert mod.java_string_hash("hello") == 99162322 and mod.java_string_hash("k") == 107
+
+
+def test_jsondb_fixture_loads():
+    """json-simple's layout as the reference writes it: HashMap key order, bare states / align tokens, Float.toString numbers
+    (one in scientific notation), `null` for the infinite calibration score, `\\/` escapes"""
+    txt = _fixture_text()
+    assert txt.startswith('{"originalTree":"((A:0.1') and '"states":core.DNAStatesShifted@1b2c6ec2,' in txt
+    d = hostio.load_jsondb(txt)
+    assert d["alphabet"] == 4 and d["k"] == 3 and d["n_branches"] == 5 and d["calibration"] is None
+    assert d["thr"] == np.float32(0.052734375) and d["thr_log10"] == np.float32(-1.2779074)
+    rows = {}
+    for r, code in enumerate(d["key_codes"].tolist()):
+        a, b = int(d["row_offsets"][r]), int(d["row_offsets"][r + 1])
+        rows[code] = list(zip(d["branch_ids"][a:b].tolist(), d["scores"][a:b].tolist()))
+    code = lambda kmer: sum("ATCG".index(c) << (2 * i) for i, c in enumerate(kmer))
+    f = lambda x: float(np.float32(x))
+    assert rows == {
+        code("ATC"): [(1, f(-0.30103)), (2, f(-0.04575749))],
+        code("AAA"): [(2, -1.0), (4, f(-0.2218487))],
+        code("GCA"): [(1, -0.75)],
+        code("TTT"): [(1, f(-1.2779074)), (3, -0.0)],
+        code("TCG"): [(2, -0.5), (3, -1.25), (4, -0.125)],
+        code("GAT"): [(1, f(-1.2041199)), (3, f(-0.69897))],
+        code("CGA"): [(4, -9.765625e-4)],
+    }
+    assert [int(c) for c in d["key_codes"]] == [code(k) for k in ("ATC", "AAA", "GCA", "TTT", "TCG", "GAT", "CGA")]  # dump order kept
+    t = d["tree"]
+    assert [n.label for n in t.nodes] == ["R", "C", "A", "B", "D"]
+    # the engine accepts it as it is (argument checks + image construction, no device needed)
+    from rappas_amd import placement
+    info = placement.validate_db(4, 3, 5, d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"], d["branch_ids"], d["scores"])
+    assert info.n_keys == 7 and info.n_entries == 13
