@@ -18,6 +18,7 @@ import hashlib
 import json
 import math
 import re
+import struct
 from dataclasses import dataclass, field
 from decimal import Decimal
 
@@ -353,6 +354,99 @@ def load_jsondb(text):
                 thr_log10=np.float32(doc["PPStarThresholdAsLog10"]), key_codes=np.array(codes, np.uint64),
                 row_offsets=np.array(off, np.uint64), branch_ids=np.array(br, np.uint16), scores=np.array(sc, np.float32),
                 tree=tree, calibration=doc.get("calibrationNormScore"), omega=doc.get("omega"))
+
+
+def load_uniondb(data):
+    """A `.union` database (SessionNext_v2.storeHash, src/main_v2/SessionNext_v2.java:109-147; read back by load, :158-207):
+    a Java serialization stream holding, in this order, block data {int k, int minK, float omega, int branchPerEdge, float
+    stateThreshold, float PPStarThreshold, float PPStarThresholdAsLog10}, the objects states, align, originalTree, extendedTree,
+    ARTree, nodeMapping, block data {float calibrationNormScore, boolean onlyFakes} and the CustomHash_v4_FastUtil81.
+    Same result dict as load_jsondb.  What is taken from the object graph:
+
+    * alphabet: the class of `states` (core.DNAStatesShifted / core.AAStates; --convertUO shows as 'U' in AAStates' char map);
+    * tree: PhyloTree.indexById (HashMap<Integer, PhyloNode>, src/tree/PhyloTree.java:39) -> per node id, label, branch length,
+      jplace edge id (src/tree/PhyloNode.java:30-37) and, from its DefaultMutableTreeNode part, parent and ordered children;
+    * rows: CustomHash_v4_FastUtil81.hash, an Object2ObjectOpenCustomHashMap<byte[], Char2FloatOpenHashMap>
+      (src/core/hash/CustomHash_v4_FastUtil81.java:36): fastutil writes its open-hash maps as defaultWriteObject() followed by
+      the entries -- writeObject(key), writeObject(value) for the outer map, writeChar(key), writeFloat(value) for a row -- `size`
+      of them.  DNA keys are compressMer bytes (DNAStatesShifted.java:115-143: little-endian 2-bit codes), AA keys one state
+      per byte.
+    PARITY UNPINNED (rappas_amd/javaser.py): never run against a file written by a JVM."""
+    from . import javaser
+    recs = javaser.parse(data)
+    blocks = b"".join(v for t, v in recs if t == "block")
+    objs = [v for t, v in recs if t == "object"]
+    if len(blocks) < 33 or len(objs) < 7:
+        raise ValueError(f"union: expected 33 bytes of scalars and 7 objects, found {len(blocks)} and {len(objs)} (a database stored "
+                         "without its hash?)")
+    k, mink, omega, bpe, st_thr, thr, thr_log10 = struct.unpack(">iififff", blocks[:28])
+    calib, only_fakes = struct.unpack(">f?", blocks[28:33])
+    states, _align, otree, _etree, _artree, _nodemap, chash = objs[:7]
+    if states.classname == "core.DNAStatesShifted":
+        alphabet, convert_uo = 4, False
+    elif states.classname == "core.AAStates":
+        alphabet = 20
+        b = states.get("b")
+        convert_uo = b is not None and any(javaser.boxed(key) in (ord("U"), "U") for key, _ in javaser.hashmap_items(b))
+    else:
+        raise ValueError(f"union: unknown States class {states.classname}")
+    # ---- original tree ----
+    index = otree.get("indexById")
+    if index is None:
+        raise ValueError("union: originalTree has no indexById map")
+    jn = {int(javaser.boxed(key)): val for key, val in javaser.hashmap_items(index)}
+    nodes = [None] * len(jn)
+    for i, o in jn.items():
+        if not 0 <= i < len(nodes):
+            raise ValueError(f"union: node id {i} outside 0..{len(nodes) - 1}")
+        n = Node(i)
+        n.label = o.get("label") or ""
+        n.bl = np.float32(o.get("branchLengthToAncestor"))
+        n.jplace_edge = int(o.get("jplaceEdgeId"))
+        nodes[i] = n
+    ident = {id(o): i for i, o in jn.items()}
+    root = None
+    for i, o in jn.items():
+        ch = o.get("children")
+        for c in (javaser.arraylist_items(ch) if ch is not None else []):
+            nodes[i].children.append(nodes[ident[id(c)]])
+            nodes[ident[id(c)]].parent = nodes[i]
+    for n in nodes:
+        if n.parent is None:
+            root = n if root is None or n.id < root.id else root
+    tree = Tree(root, nodes)
+    # ---- hash ----
+    outer = chash.get("hash")
+    if outer is None:
+        raise ValueError("union: CustomHash_v4_FastUtil81 without its map")
+    oname = "it.unimi.dsi.fastutil.objects.Object2ObjectOpenCustomHashMap"
+    rname = "it.unimi.dsi.fastutil.chars.Char2FloatOpenHashMap"
+    kv = outer.objects(oname)
+    n_keys = int(outer.get("size"))
+    if len(kv) != 2 * n_keys:
+        raise ValueError(f"union: outer map announces {n_keys} entries, stream holds {len(kv) // 2}")
+    codes, off, br, sc = [], [0], [], []
+    for key, row in zip(kv[0::2], kv[1::2]):
+        raw = key.raw
+        if alphabet == 4:
+            code = int.from_bytes(raw, "little")  # compressMer bytes: base i at bits 2*(i%4) of byte i/4
+            if code >> (2 * k):
+                raise ValueError("union: DNA key has bits beyond 2k")
+        else:
+            code = sum((b & 0xFF) << (5 * i) for i, b in enumerate(raw))
+        codes.append(code)
+        m = int(row.get("size"))
+        blob = row.block(rname)
+        if len(blob) != 6 * m:
+            raise ValueError(f"union: row announces {m} entries, stream holds {len(blob)} bytes")
+        for e in range(m):
+            node, v = struct.unpack_from(">Hf", blob, 6 * e)
+            br.append(node)
+            sc.append(v)
+        off.append(len(br))
+    return dict(alphabet=alphabet, convert_uo=convert_uo, k=k, n_branches=len(nodes), thr=np.float32(thr), thr_log10=np.float32(thr_log10),
+                key_codes=np.array(codes, np.uint64), row_offsets=np.array(off, np.uint64), branch_ids=np.array(br, np.uint16),
+                scores=np.array(sc, np.float32), tree=tree, calibration=calib, omega=omega, only_fakes=only_fakes)
 
 
 def dump_jsondb(db, newick, omega=1.5):

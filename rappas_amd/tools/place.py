@@ -15,11 +15,12 @@ from ..placement import PhyloKmerDB, PlacementProcess
 
 
 def place_file(db_text, fasta_text, keep_at_most=7, keep_factor=0.01, amb="mean", ns_bound=float("-inf"), guppy=False,
-               call_string="", device=0):
-    d = hostio.load_jsondb(db_text)
+               call_string="", device=0, union=False):
+    """db_text: the bytes of a --jsondb dump, or (union=True) of a Java-serialized .union database"""
+    d = hostio.load_uniondb(db_text) if union else hostio.load_jsondb(db_text)
     tree = d["tree"]
     db = PhyloKmerDB(d["alphabet"], d["k"], d["n_branches"], d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"],
-                     d["branch_ids"], d["scores"], device=device)
+                     d["branch_ids"], d["scores"], device=device, convert_uo=d.get("convert_uo", False))
     try:
         records = hostio.read_fasta(fasta_text)
         unique, names = hostio.dedup_reads(records)
@@ -36,7 +37,9 @@ def place_file(db_text, fasta_text, keep_at_most=7, keep_factor=0.01, amb="mean"
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="rappas_amd.tools.place", description=__doc__.splitlines()[0])
-    ap.add_argument("--jsondb", required=True, help="database dump written by the reference's --jsondb")
+    g = ap.add_mutually_exclusive_group(required=True)
+    g.add_argument("--jsondb", help="database dump written by the reference's --jsondb")
+    g.add_argument("--uniondb", help="the reference's own database file (DB.union, Java serialization; SessionNext_v2.java:109-207)")
     ap.add_argument("--fasta", required=True, help="query reads (-q)")
     ap.add_argument("--out", required=True, help="output .jplace")
     ap.add_argument("--keep-at-most", type=int, default=7)
@@ -47,13 +50,13 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--logs", default=None, help="directory of notplaced_<query>.tsv (default: logs/ next to --out, like the reference's workdir/logs)")
     a = ap.parse_args(argv)
-    with open(a.jsondb, "rb") as f:
+    with open(a.jsondb or a.uniondb, "rb") as f:
         db_text = f.read()
     with open(a.fasta, "rb") as f:
         fasta_text = f.read()
     call = "".join(" " + x for x in (argv if argv is not None else sys.argv[1:]))
     doc, res = place_file(db_text, fasta_text, a.keep_at_most, a.keep_factor, a.amb, a.nsbound, a.guppy_compat, call,
-                          a.device)
+                          a.device, union=a.uniondb is not None)
     with open(a.out, "w") as f:
         f.write(doc)
     logs = a.logs if a.logs is not None else os.path.join(os.path.dirname(os.path.abspath(a.out)), "logs")

@@ -1,4 +1,4 @@
-"""Authoring script of tests/golden/jsondb_toy.json: a `--jsondb` dump written out BY HAND from the reference's Java, not by
+"""Authoring script of tests/golden/jsondb/jsondb_toy.json: a `--jsondb` dump written out BY HAND from the reference's Java, not by
 rappas_amd.hostio.dump_jsondb (which the loaders were only ever tested against before).
 
 What the reference does (src/main_v2/SessionNext_v2.java:214-270): a json-simple 1.1 `JSONObject` -- which `extends HashMap`
@@ -22,7 +22,7 @@ documented behaviour:
 
 The toy session: DNA, k = 3, omega = 1.5, tree ((A:0.1,B:0.2)C:0.3,D:0.4)R; (node ids in order of appearance R0 C1 A2 B3 D4,
 NewickReader.java:76-160), seven k-mers.  Every float below is typed as Java prints it (shortest digits that identify the
-float; scientific notation below 1e-3).  Run: python tests/golden/make_jsondb_fixture.py
+float; scientific notation below 1e-3).  Run: python tests/golden/jsondb/make_jsondb_fixture.py
 """
 import os
 

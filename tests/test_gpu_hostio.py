@@ -139,3 +139,29 @@ def test_notplaced_log_is_written_by_both_drivers(tmp_path):
     r = subprocess.run([exe] + args, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert log.read_text() == py
+
+
+def test_place_tool_accepts_a_union_database(tmp_path):
+    """--uniondb: the reference's own database format read without a JVM (rappas_amd/javaser.py), same .jplace as --jsondb"""
+    from tests import javaser_writer as JW
+    db = synth.make_db(4, 6, 75, 800, 6000, seed=21)
+    nwk = synth.make_newick(75, seed=6)
+    tree = hostio.parse_newick(nwk)
+    spec = [(n.id, n.label, float(n.bl), n.jplace_edge, n.parent.id if n.parent is not None else None) for n in tree.nodes]
+    # children must be listed in tree order: parse order == id order for this writer
+    rows = []
+    for r, code in enumerate(db.key_codes.tolist()):
+        a, b = int(db.row_offsets[r]), int(db.row_offsets[r + 1])
+        key = int(code).to_bytes(2, "little")  # compressMer of a 6-mer: 12 bits in 2 bytes
+        rows.append((key, [(int(db.branch_ids[e]), float(db.scores[e])) for e in range(a, b)]))
+    blob = JW.union_stream(4, 6, 1.5, float(db.thr), float(db.thr_log10), JW.phylo_tree(spec, tree.rooted), rows)
+    (tmp_path / "DB.union").write_bytes(blob)
+    (tmp_path / "db.json").write_text(hostio.dump_jsondb(db, nwk))
+    fasta, _ = _fasta(db, 200, 120, seed=4)
+    (tmp_path / "q.fasta").write_text(fasta)
+    common = ["--fasta", str(tmp_path / "q.fasta")]
+    assert place_tool.main(["--uniondb", str(tmp_path / "DB.union"), "--out", str(tmp_path / "u.jplace")] + common) == 0
+    assert place_tool.main(["--jsondb", str(tmp_path / "db.json"), "--out", str(tmp_path / "j.jplace")] + common) == 0
+    u = json.loads((tmp_path / "u.jplace").read_text())
+    j = json.loads((tmp_path / "j.jplace").read_text())
+    assert u["placements"] == j["placements"] and u["tree"] == j["tree"] and len(u["placements"]) > 100

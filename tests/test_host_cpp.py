@@ -92,10 +92,10 @@ def test_string_escaping_follows_json_simple():
 
 
 def test_native_loader_reads_the_fixture_authored_from_the_java(rk_place):
-    """tests/golden/jsondb_toy.json (written by hand from SessionNext_v2.saveToJSON + json-simple, not by dump_jsondb):
+    """tests/golden/jsondb/jsondb_toy.json (written by hand from SessionNext_v2.saveToJSON + json-simple, not by dump_jsondb):
     the C++ loader gives the rows typed into the authoring script, in the dump's order"""
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsondb_toy.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsondb", "jsondb_toy.json")
     out = run(rk_place, "--load-jsondb", path).splitlines()
     assert out[0] == "3 0.052734375 -1.2779074 7 13"
     assert out[1] == "((A:0.100000000000,B:0.200000000000)C:0.300000000000,D:0.400000000000)R;"

@@ -143,17 +143,17 @@ def test_jsondb_rejects_non_dna_kmers():
         hostio.load_jsondb(txt)
 
 
-# ---- the --jsondb fixture authored from the Java (tests/golden/make_jsondb_fixture.py), not from dump_jsondb ----
+# ---- the --jsondb fixture authored from the Java (tests/golden/jsondb/make_jsondb_fixture.py), not from dump_jsondb ----
 def _fixture_text():
     import os
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsondb")
     return open(os.path.join(here, "jsondb_toy.json")).read()
 
 
 def test_jsondb_fixture_is_what_its_authoring_script_writes():
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_jsondb_fixture.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsondb", "make_jsondb_fixture.py")
     spec = importlib.util.spec_from_file_location("make_jsondb_fixture", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
