@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--verify", type=int, default=2000, help="reads checked against the oracle before timing")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (host buffers through rk_place_batch / rk_place_batch_packed)")
+    ap.add_argument("--pcie-reads", type=int, default=4_000_000, help="reads of the PCIe-inclusive leg (rank 0, N=1)")
     ap.add_argument("--db-scale", type=float, default=1.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse the multi-rank path on one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
@@ -308,6 +310,35 @@ def main():
                          "kernel_ms": kern_avg_s * 1e3, "kernel": db.kernel_name().split("<")[0]},
             "verified_vs_oracle": verified,
         }
+        if not a.no_pcie and n_gpus == 1:
+            # ---- the boundary RAPPAS would call: host buffers in, host buffers out (never `value`) ----
+            # pageable numpy arrays (what a JVM heap array looks like to the library), result arrays allocated once and reused
+            npc = min(a.pcie_reads, n_reads)
+            h_packed = packed[:npc].cpu().numpy().view(np.uint32)
+            h_seq, h_off = unpack_to_ascii(alphabet, h_packed, rlen)
+            reuse = ra.Placements(np.zeros(npc, np.uint8), np.zeros((npc, K), np.uint16), np.zeros((npc, K), np.float32),
+                                  np.zeros((npc, K), np.float64), np.zeros(npc, np.uint32), {})
+
+            def timed(fn, reps=3):
+                fn()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                return npc * reps / (time.perf_counter() - t0)
+            r_packed = timed(lambda: pp.processQueriesPacked(h_packed, fixed_len=rlen, keepAtMost=K, out=reuse))
+            dev_n = out["n_rows"][:npc].cpu().numpy()
+            same = bool(np.array_equal(reuse.n_rows, dev_n) and np.array_equal(reuse.branch, out["branch"][:npc].cpu().numpy().view(np.uint16)))
+            r_ascii = timed(lambda: pp.processQueries(h_seq, h_off, keepAtMost=K, out=reuse))
+            t0 = time.perf_counter()
+            pp.pack_reads_host(h_seq, h_off, max_len=rlen)
+            r_pack = npc / (time.perf_counter() - t0)
+            out_b = 1 + K * 14 + 4
+            line["pcie_inclusive"] = {
+                "packed_host": {"value": r_packed, "unit": "reads/s", "entry": "rk_place_batch_packed", "bytes_in_per_read": wpr * 4, "bytes_out_per_read": out_b},
+                "ascii_host": {"value": r_ascii, "unit": "reads/s", "entry": "rk_place_batch", "bytes_in_per_read": rlen + 8, "bytes_out_per_read": out_b},
+                "host_packer": {"value": r_pack, "unit": "reads/s", "entry": "rk_pack_reads_host", "threads": min(os.cpu_count() or 1, 16)},
+                "sample": f"first {npc} reads of the batch, pageable host arrays, result arrays reused, 3 calls after one warm-up",
+                "equals_device_path": same}
         if not a.no_cpu_baseline and n_gpus == 1:
             # bounded sample: about 10 s of single-thread work (the oracle does ~1.6e7 row entries per second)
             ns = min(a.cpu_sample, n_reads, max(64 if spec is not None else 2000, int(1.6e8 / max(1.0, H_mean))))

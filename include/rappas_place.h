@@ -158,6 +158,19 @@ int rk_db_create_synth(const rk_synth_desc *desc, rk_db **out);
 int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                    const uint64_t *seq_off, rk_result *out, rk_counters *counters);
 
+/* The same for reads the host has already packed (2 bits per base / 5 per residue, symbol i at bits [i*b, (i+1)*b) of the
+ * record's little-endian bit string -- the layout rk_pack_reads_device produces): 38 instead of 150 bytes per 150-bp read cross
+ * PCIe.  lens NULL => every read has fixed_len symbols; flags NULL => no read carries BAD_CHAR / AMBIGUOUS.  seq_ascii / seq_off
+ * (both or neither) are consulted only for chunks that hold a read flagged AMBIGUOUS (the ambiguity path of
+ * PlacementProcess.java:1129-1236 works on characters); without them such reads come back unplaced with the flag set.
+ * rk_pack_reads_host is the matching host-side packer (AmbigSequenceKnife.java:103-130 char -> state, threaded; n_threads 0 =
+ * auto): it writes the records, lengths and flags exactly as the device packer does. */
+int rk_place_batch_packed(rk_db *db, const rk_params *p, uint64_t n_reads, const uint32_t *packed, uint32_t words_per_read,
+                          const uint32_t *lens, uint32_t fixed_len, const uint32_t *flags, const uint8_t *seq_ascii,
+                          const uint64_t *seq_off, rk_result *out, rk_counters *counters);
+int rk_pack_reads_host(const rk_db *db, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off, uint32_t words_per_read,
+                       uint32_t *packed, uint32_t *lens, uint32_t *flags, uint32_t n_threads);
+
 /* The same over several GPUs from ONE host process (RAPPAS is a single JVM): dbs[g] are handles of the same database created
  * on different devices (rk_db_create with desc.device = g); the batch is cut into n_dbs contiguous shards, shard g goes to
  * dbs[g] on its own host thread, and every shard writes its slice of the caller's result arrays -- reads are independent

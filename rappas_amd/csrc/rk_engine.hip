@@ -182,13 +182,13 @@ struct rk_workspace {
     GrowBuf ascii, off, packed, lens, flags, nrows, branch, score, lwr, oflags;
     // page-locked staging for callers that hand over pageable memory (a JVM heap array, a numpy array): copies to / from
     // it run on a few host threads, the DMA itself is then asynchronous and overlaps the other workspace's chunk
-    PinBuf h_ascii, h_off, h_nrows, h_branch, h_score, h_lwr, h_oflags;
+    PinBuf h_ascii, h_off, h_packed, h_nrows, h_branch, h_score, h_lwr, h_oflags;
     bool pending = false;       // results of the last chunk are still in the staging buffers
     uint64_t pend_r0 = 0, pend_n = 0;
     hipStream_t stream = nullptr;
     void release() {
         for (GrowBuf *b : {&ascii, &off, &packed, &lens, &flags, &nrows, &branch, &score, &lwr, &oflags}) b->release();
-        for (PinBuf *b : {&h_ascii, &h_off, &h_nrows, &h_branch, &h_score, &h_lwr, &h_oflags}) b->release();
+        for (PinBuf *b : {&h_ascii, &h_off, &h_packed, &h_nrows, &h_branch, &h_score, &h_lwr, &h_oflags}) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -1096,17 +1096,28 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
 // host-buffer entry point: chunked, two workspaces on two streams so that the upload of chunk c+1 overlaps the
 // kernels / download of chunk c; device buffers are kept (grow-only) in the rk_db between calls
 // ------------------------------------------------------------------------------------------------
-extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
-                              const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
-    if (!db || !out) return fail(RK_ERR_INVALID, "rk_place_batch: null argument");
-    int rc = check_params(p);
-    if (rc) return rc;
+// what the host hands over: ASCII reads (packed on the device) or records already packed on the host (rk_pack_reads_host)
+struct HostInput {
+    const uint8_t *ascii = nullptr;   // concatenated reads; with `packed` set: only consulted for reads flagged AMBIGUOUS
+    const uint64_t *off = nullptr;    // [n + 1]
+    const uint32_t *packed = nullptr; // [n][wpr]
+    uint32_t wpr = 0;
+    const uint32_t *lens = nullptr;   // [n] or NULL (fixed_len)
+    uint32_t fixed_len = 0;
+    const uint32_t *flags = nullptr;  // [n] or NULL
+};
+
+static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const HostInput &in, rk_result *out, rk_counters *counters,
+                      const char *who) {
+    const bool packed_in = in.packed != nullptr;
+    const uint8_t *seq_ascii = in.ascii;
+    const uint64_t *seq_off = in.off;
     rk_counters ct{};
     if (n_reads == 0) { if (counters) *counters = ct; return RK_OK; }
-    if (!seq_ascii || !seq_off) return fail(RK_ERR_INVALID, "rk_place_batch: null reads");
-    if (!out->n_rows || !out->branch || !out->score || !out->lwr || !out->flags) return fail(RK_ERR_INVALID, "rk_place_batch: null result array");
-    for (uint64_t r = 0; r < n_reads; r++)
-        if (seq_off[r + 1] < seq_off[r]) return fail(RK_ERR_INVALID, "rk_place_batch: seq_off not monotone at read %llu", (unsigned long long)r);
+    if (!out->n_rows || !out->branch || !out->score || !out->lwr || !out->flags) return fail(RK_ERR_INVALID, "%s: null result array", who);
+    if (seq_off)
+        for (uint64_t r = 0; r < n_reads; r++)
+            if (seq_off[r + 1] < seq_off[r]) return fail(RK_ERR_INVALID, "%s: seq_off not monotone at read %llu", who, (unsigned long long)r);
     std::lock_guard<std::mutex> lock(db->host_mutex);  // the two workspaces belong to the db: one host call at a time
     HIP_TRY(hipSetDevice(db->info.device));
     const uint32_t K = p->keep_at_most;
@@ -1120,7 +1131,7 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
         if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
         return at.type == hipMemoryTypeHost;
     };
-    const bool in_pinned = is_pinned(seq_ascii);
+    const bool in_pinned = packed_in ? is_pinned(in.packed) : is_pinned(seq_ascii);
     const bool out_pinned = is_pinned(out->n_rows) && is_pinned(out->branch) && is_pinned(out->score) && is_pinned(out->lwr) && is_pinned(out->flags);
     auto drain = [&](rk_workspace &w) {  // staged results of the workspace's last chunk -> the caller's arrays
         if (!w.pending) return;
@@ -1137,14 +1148,24 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
     int status = RK_OK;
     while (r0 < n_reads && status == RK_OK) {
         uint64_t r1 = r0, max_len = 0;
-        while (r1 < n_reads && r1 - r0 < max_chunk_reads && (seq_off[r1 + 1] - seq_off[r0] <= max_chunk_bytes || r1 == r0)) {
-            uint64_t L = seq_off[r1 + 1] - seq_off[r1];
-            if (L > max_len) max_len = L;
-            r1++;
+        if (packed_in) {
+            r1 = std::min(n_reads, r0 + max_chunk_reads);
+        } else {
+            while (r1 < n_reads && r1 - r0 < max_chunk_reads && (seq_off[r1 + 1] - seq_off[r0] <= max_chunk_bytes || r1 == r0)) {
+                uint64_t L = seq_off[r1 + 1] - seq_off[r1];
+                if (L > max_len) max_len = L;
+                r1++;
+            }
         }
-        const uint64_t n = r1 - r0, nbytes = seq_off[r1] - seq_off[r0];
-        if (max_len > 0x7FFFFFFFull / 8) { status = fail(RK_ERR_UNSUPPORTED, "rk_place_batch: read longer than 2^28 symbols"); break; }
-        const uint32_t wpr = rk_packed_words(db, (uint32_t)max_len);
+        const uint64_t n = r1 - r0;
+        if (max_len > 0x7FFFFFFFull / 8) { status = fail(RK_ERR_UNSUPPORTED, "%s: read longer than 2^28 symbols", who); break; }
+        const uint32_t wpr = packed_in ? in.wpr : rk_packed_words(db, (uint32_t)max_len);
+        // packed input: the ASCII of the chunk travels only if one of its reads carries the AMBIGUOUS flag (the ambiguity kernel
+        // works on characters); otherwise 38 instead of 150 bytes per 150-bp read cross the link
+        bool need_ascii = !packed_in;
+        if (packed_in && in.flags && seq_ascii && seq_off)
+            for (uint64_t r = r0; r < r1 && !need_ascii; r++) need_ascii = (in.flags[r] & RK_FLAG_AMBIGUOUS) != 0;
+        const uint64_t nbytes = need_ascii ? seq_off[r1] - seq_off[r0] : 0;
         rk_workspace &w = db->ws[chunk_no & 1];
         hipStream_t s = w.stream;
         // the workspace was last used two chunks ago: its downloads must have landed before it is overwritten
@@ -1153,8 +1174,6 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
         drain(w);
 #define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
 #define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
-        WS_TRY(w.ascii.reserve(nbytes));
-        WS_TRY(w.off.reserve((n + 1) * 8));
         WS_TRY(w.packed.reserve(n * wpr * 4));
         WS_TRY(w.lens.reserve(n * 4));
         WS_TRY(w.flags.reserve(n * 4));
@@ -1163,25 +1182,51 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
         WS_TRY(w.score.reserve(n * K * 4));
         WS_TRY(w.lwr.reserve(n * K * 8));
         WS_TRY(w.oflags.reserve(n * 4));
-        WS_TRY(w.h_off.reserve((n + 1) * 8));
-        {
+        if (need_ascii) {
+            WS_TRY(w.ascii.reserve(nbytes));
+            WS_TRY(w.off.reserve((n + 1) * 8));
+            WS_TRY(w.h_off.reserve((n + 1) * 8));
             uint64_t *ho = w.h_off.as<uint64_t>();
             for (uint64_t i = 0; i <= n; i++) ho[i] = seq_off[r0 + i] - seq_off[r0];
+            if (!packed_in && in_pinned) {
+                if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
+            } else if (nbytes) {
+                WS_TRY(w.h_ascii.reserve(nbytes));
+                parallel_copy(w.h_ascii.p, seq_ascii + seq_off[r0], nbytes);
+                WS_HIP(hipMemcpyAsync(w.ascii.p, w.h_ascii.p, nbytes, hipMemcpyHostToDevice, s));
+            }
+            WS_HIP(hipMemcpyAsync(w.off.p, w.h_off.p, (n + 1) * 8, hipMemcpyHostToDevice, s));
         }
-        if (in_pinned) {
-            if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
-        } else if (nbytes) {
-            WS_TRY(w.h_ascii.reserve(nbytes));
-            parallel_copy(w.h_ascii.p, seq_ascii + seq_off[r0], nbytes);
-            WS_HIP(hipMemcpyAsync(w.ascii.p, w.h_ascii.p, nbytes, hipMemcpyHostToDevice, s));
+        if (packed_in) {
+            // packed records (+ lengths, flags): straight from page-locked caller memory, else through the staging buffer
+            const size_t pb = n * wpr * 4, lb = in.lens ? n * 4 : 0, fb = in.flags ? n * 4 : 0;
+            if (in_pinned) {
+                WS_HIP(hipMemcpyAsync(w.packed.p, in.packed + r0 * wpr, pb, hipMemcpyHostToDevice, s));
+            } else {
+                WS_TRY(w.h_packed.reserve(pb + lb + fb));
+                parallel_copy(w.h_packed.p, in.packed + r0 * wpr, pb);
+                WS_HIP(hipMemcpyAsync(w.packed.p, w.h_packed.p, pb, hipMemcpyHostToDevice, s));
+            }
+            // (lengths and flags are small: pageable copies are fine, but they must not be read after this call returns
+            //  -- the staging buffer keeps them when the caller's memory is pageable)
+            if (lb) {
+                if (in_pinned) WS_HIP(hipMemcpyAsync(w.lens.p, in.lens + r0, lb, hipMemcpyHostToDevice, s));
+                else { memcpy((char *)w.h_packed.p + pb, in.lens + r0, lb); WS_HIP(hipMemcpyAsync(w.lens.p, (char *)w.h_packed.p + pb, lb, hipMemcpyHostToDevice, s)); }
+            }
+            if (fb) {
+                if (in_pinned) WS_HIP(hipMemcpyAsync(w.flags.p, in.flags + r0, fb, hipMemcpyHostToDevice, s));
+                else { memcpy((char *)w.h_packed.p + pb + lb, in.flags + r0, fb); WS_HIP(hipMemcpyAsync(w.flags.p, (char *)w.h_packed.p + pb + lb, fb, hipMemcpyHostToDevice, s)); }
+            }
+        } else {
+            WS_TRY(rk_pack_reads_device(db, n, w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), wpr, w.packed.as<uint32_t>(),
+                                        w.lens.as<uint32_t>(), w.flags.as<uint32_t>(), s));
         }
-        WS_HIP(hipMemcpyAsync(w.off.p, w.h_off.p, (n + 1) * 8, hipMemcpyHostToDevice, s));
-        WS_TRY(rk_pack_reads_device(db, n, w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), wpr, w.packed.as<uint32_t>(),
-                                    w.lens.as<uint32_t>(), w.flags.as<uint32_t>(), s));
         {
             rk_result dres{w.nrows.as<uint8_t>(), w.branch.as<uint16_t>(), w.score.as<float>(), w.lwr.as<double>(), w.oflags.as<uint32_t>()};
-            WS_TRY(rk_place_packed_device(db, p, n, w.packed.as<uint32_t>(), wpr, w.lens.as<uint32_t>(), 0, w.flags.as<uint32_t>(),
-                                          w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), &dres, s));
+            const uint32_t *d_lens = (!packed_in || in.lens) ? w.lens.as<uint32_t>() : nullptr;
+            const uint32_t *d_flags = (!packed_in || in.flags) ? w.flags.as<uint32_t>() : nullptr;
+            WS_TRY(rk_place_packed_device(db, p, n, w.packed.as<uint32_t>(), wpr, d_lens, packed_in ? in.fixed_len : 0, d_flags,
+                                          need_ascii ? w.ascii.as<uint8_t>() : nullptr, need_ascii ? w.off.as<uint64_t>() : nullptr, &dres, s));
         }
         if (out_pinned) {
             WS_HIP(hipMemcpyAsync(out->n_rows + r0, w.nrows.p, n, hipMemcpyDeviceToHost, s));
@@ -1225,6 +1270,77 @@ done:
         if (f & RK_FLAG_AMBIGUOUS) ct.ambiguous++;
     }
     if (counters) *counters = ct;
+    return RK_OK;
+}
+
+extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
+                              const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
+    if (!db || !out) return fail(RK_ERR_INVALID, "rk_place_batch: null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_reads && (!seq_ascii || !seq_off)) return fail(RK_ERR_INVALID, "rk_place_batch: null reads");
+    HostInput in;
+    in.ascii = seq_ascii; in.off = seq_off;
+    return place_host(db, p, n_reads, in, out, counters, "rk_place_batch");
+}
+
+extern "C" int rk_place_batch_packed(rk_db *db, const rk_params *p, uint64_t n_reads, const uint32_t *packed, uint32_t words_per_read,
+                                     const uint32_t *lens, uint32_t fixed_len, const uint32_t *flags, const uint8_t *seq_ascii,
+                                     const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
+    if (!db || !out) return fail(RK_ERR_INVALID, "rk_place_batch_packed: null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_reads && (!packed || words_per_read == 0)) return fail(RK_ERR_INVALID, "rk_place_batch_packed: null packed reads");
+    if (!lens && (uint64_t)fixed_len * db->info.bits_per_symbol > (uint64_t)words_per_read * 32)
+        return fail(RK_ERR_INVALID, "rk_place_batch_packed: fixed_len=%u does not fit %u words", fixed_len, words_per_read);
+    if ((seq_ascii == nullptr) != (seq_off == nullptr)) return fail(RK_ERR_INVALID, "rk_place_batch_packed: seq_ascii and seq_off go together");
+    HostInput in;
+    in.ascii = seq_ascii; in.off = seq_off; in.packed = packed; in.wpr = words_per_read; in.lens = lens; in.fixed_len = fixed_len; in.flags = flags;
+    return place_host(db, p, n_reads, in, out, counters, "rk_place_batch_packed");
+}
+
+// AmbigSequenceKnife.initTables' char -> state part (AmbigSequenceKnife.java:103-130) on the host, for callers that would rather
+// ship 2 / 5 bits per symbol over PCIe than 8: the same records, lengths and flags pack_reads_kernel produces.
+extern "C" int rk_pack_reads_host(const rk_db *db, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off, uint32_t words_per_read,
+                                  uint32_t *packed, uint32_t *lens, uint32_t *flags, uint32_t n_threads) {
+    if (!db || !seq_off || !packed || !lens || !flags || words_per_read == 0) return fail(RK_ERR_INVALID, "rk_pack_reads_host: null/zero argument");
+    if (n_reads && !seq_ascii && seq_off[n_reads]) return fail(RK_ERR_INVALID, "rk_pack_reads_host: null reads");
+    Alphabet A;
+    build_alphabet(db->info.alphabet, db->convert_uo != 0, A);
+    const uint32_t bits = db->info.bits_per_symbol, k = db->info.k;
+    const uint32_t cap_syms = (words_per_read * 32u) / bits;
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = n_threads ? n_threads : std::max(1u, std::min(hw ? hw : 1u, 16u));
+    if (n_reads < 4096) T = 1;
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; r++) {
+            const uint64_t o0 = seq_off[r], full = seq_off[r + 1] - o0;
+            const uint32_t R = full > cap_syms ? cap_syms : (uint32_t)full;
+            uint32_t fl = 0;
+            if (full > cap_syms) fl |= RK_FLAG_TOO_LONG;
+            if (R < k) fl |= RK_FLAG_TOO_SHORT;
+            uint32_t *rec = packed + r * words_per_read;
+            uint64_t acc = 0;   // bit buffer, flushed 32 bits at a time
+            uint32_t have = 0, w = 0;
+            for (uint32_t i = 0; i < R; i++) {
+                const uint32_t c = A.table[seq_ascii[o0 + i]];
+                uint32_t st = c;
+                if (c == 0xFF) { fl |= RK_FLAG_BAD_CHAR; st = 0; }
+                else if (c & 0x80) { fl |= RK_FLAG_AMBIGUOUS; st = 0; }
+                acc |= (uint64_t)st << have;
+                have += bits;
+                if (have >= 32) { rec[w++] = (uint32_t)acc; acc >>= 32; have -= 32; }
+            }
+            if (w < words_per_read) rec[w++] = (uint32_t)acc;
+            while (w < words_per_read) rec[w++] = 0;
+            lens[r] = R;
+            flags[r] = fl;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work, n_reads * t / T, n_reads * (t + 1) / T);
+    work(0, n_reads / T);
+    for (std::thread &x : th) x.join();
     return RK_OK;
 }
 

@@ -141,20 +141,57 @@ class PlacementProcess:
         return rk_params(keepAtMost, keepFactor, amb, self.ns_bound)
 
     def processQueries(self, seq, seq_off, keepAtMost=7, keepFactor=0.01, treatAmbiguities=True,
-                       treatAmbiguitiesWithMax=False):
+                       treatAmbiguitiesWithMax=False, out=None):
         """seq: uint8 ASCII of all reads concatenated (no gap stripping, as FASTAPointer(q,false) delivers them);
-        seq_off: uint64 [n+1].  Defaults = src/main_v2/ArgumentsParser_v2.java:87-91."""
+        seq_off: uint64 [n+1].  Defaults = src/main_v2/ArgumentsParser_v2.java:87-91.  `out`: a Placements to reuse."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
         n = seq_off.shape[0] - 1
         K = keepAtMost
-        out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
-                         np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
+        if out is None:
+            out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
+                             np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
         res = rk_result(_ptr(out.n_rows), _ptr(out.branch), _ptr(out.score), _ptr(out.lwr), _ptr(out.flags))
         p = self._params(keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax)
         ct = rk_counters()
         _lib.check(self._lib.rk_place_batch(self.db.handle, C.byref(p), n, _ptr(seq), _ptr(seq_off), C.byref(res),
                                             C.byref(ct)))
+        out.counters = {f: getattr(ct, f) for f, _ in rk_counters._fields_}
+        return out
+
+    def pack_reads_host(self, seq, seq_off, max_len=None, threads=0):
+        """rk_pack_reads_host: ASCII reads -> (packed u32 [n, wpr], lens u32 [n], flags u32 [n]) on the host, the records the
+        device packer would produce (AmbigSequenceKnife.java:103-130 char -> state)."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        n = seq_off.shape[0] - 1
+        if max_len is None:
+            max_len = int((seq_off[1:] - seq_off[:-1]).max()) if n else 0
+        wpr = self.db.packed_words(max_len)
+        packed = np.zeros((n, wpr), np.uint32)
+        lens = np.zeros(n, np.uint32)
+        flags = np.zeros(n, np.uint32)
+        _lib.check(self._lib.rk_pack_reads_host(self.db.handle, n, _ptr(seq), _ptr(seq_off), wpr, _ptr(packed), _ptr(lens), _ptr(flags), threads))
+        return packed, lens, flags
+
+    def processQueriesPacked(self, packed, lens=None, fixed_len=0, flags=None, seq=None, seq_off=None, keepAtMost=7, keepFactor=0.01,
+                             treatAmbiguities=True, treatAmbiguitiesWithMax=False, out=None):
+        """rk_place_batch_packed: processQueries for reads already packed on the host (38 instead of 150 bytes per 150-bp read over
+        PCIe); seq / seq_off are only needed for reads flagged AMBIGUOUS.  `out`: a Placements whose arrays are reused."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        n, wpr = packed.shape
+        K = keepAtMost
+        if out is None:
+            out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
+                             np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
+        res = rk_result(_ptr(out.n_rows), _ptr(out.branch), _ptr(out.score), _ptr(out.lwr), _ptr(out.flags))
+        p = self._params(keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax)
+        ct = rk_counters()
+        keep = [np.ascontiguousarray(a, dtype=dt) if a is not None else None
+                for a, dt in ((lens, np.uint32), (flags, np.uint32), (seq, np.uint8), (seq_off, np.uint64))]
+        ptrs = [None if a is None else _ptr(a) for a in keep]
+        _lib.check(self._lib.rk_place_batch_packed(self.db.handle, C.byref(p), n, _ptr(packed), wpr, ptrs[0], fixed_len, ptrs[1],
+                                                   ptrs[2], ptrs[3], C.byref(res), C.byref(ct)))
         out.counters = {f: getattr(ct, f) for f, _ in rk_counters._fields_}
         return out
 

@@ -530,3 +530,58 @@ def test_failed_shard_is_requeued_on_a_healthy_device(c2_small, monkeypatch):
     finally:
         for d in dbs:
             d.close()
+
+
+# ---- host-packed entry point (rk_pack_reads_host + rk_place_batch_packed) ----
+@pytest.mark.parametrize("alphabet,cfg", [(4, "C1"), (20, "C4")])
+def test_host_packer_equals_the_device_packer_and_numpy(alphabet, cfg):
+    sdb = synth.make_config_db(cfg, scale=0.2 if cfg == "C4" else 1.0)
+    seq, off = synth.make_reads(alphabet, 5000, 120, seed=12, amb_rate=0.004, bad_rate=0.01, var_len=60)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    try:
+        pp = ra.PlacementProcess(db)
+        packed, lens, flags = pp.pack_reads_host(seq, off)
+        want, wlens = synth.pack_reads_numpy(alphabet, seq, off, words_per_read=packed.shape[1])
+        assert np.array_equal(packed, want) and np.array_equal(lens, wlens)
+        import torch
+        dpk, dl, df = pp.pack_reads(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), int(lens.max()))
+        assert np.array_equal(dpk.cpu().numpy().view(np.uint32), packed)
+        assert np.array_equal(dl.cpu().numpy().view(np.uint32), lens) and np.array_equal(df.cpu().numpy().view(np.uint32), flags)
+    finally:
+        db.close()
+
+
+@pytest.mark.parametrize("amb", ["mean", "skip"])
+def test_packed_host_entry_equals_the_ascii_entry(c2_small, amb):
+    """rk_place_batch_packed over records packed on the host == rk_place_batch over the characters (and == the oracle); three
+    chunks, ambiguous and bad reads included; without the characters ambiguous reads come back unplaced with their flag"""
+    sdb, odb = c2_small
+    n = (1 << 20) + 4097
+    seq, off = synth.make_reads(4, n, 150, seed=5, amb_rate=0.0002, bad_rate=0.0005, var_len=20)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    try:
+        pp = ra.PlacementProcess(db)
+        kw = dict(treatAmbiguities=amb != "skip")
+        want = pp.processQueries(seq, off, **kw)
+        packed, lens, flags = pp.pack_reads_host(seq, off)
+        got = pp.processQueriesPacked(packed, lens=lens, flags=flags, seq=seq, seq_off=off, **kw)
+        for f in ("n_rows", "branch", "flags", "lwr"):
+            assert np.array_equal(getattr(got, f), getattr(want, f)), f
+        assert np.array_equal(got.score.view(np.uint32), want.score.view(np.uint32)) and got.counters == want.counters
+        sl = slice(n - 3000, n)
+        ref = odb.place(seq[int(off[sl.start]):], off[sl.start:] - off[sl.start], amb_mode=GU.AMB[amb])
+        part = ra.Placements(got.n_rows[sl], got.branch[sl], got.score[sl], got.lwr[sl], got.flags[sl], {})
+        compare_with_oracle(part, ref, odb, seq[int(off[sl.start]):], off[sl.start:] - off[sl.start], amb_mode=GU.AMB[amb])
+        # no characters handed over: reads with an ambiguity code are reported unplaced, everything else is unchanged
+        bare = pp.processQueriesPacked(packed, lens=lens, flags=flags, **kw)
+        is_amb = (flags & _lib.RK_FLAG_AMBIGUOUS) != 0
+        assert is_amb.sum() > 100 and (bare.n_rows[is_amb] == 0).all() and ((bare.flags[is_amb] & _lib.RK_FLAG_AMBIGUOUS) != 0).all()
+        assert np.array_equal(bare.branch[~is_amb], want.branch[~is_amb]) and np.array_equal(bare.n_rows[~is_amb], want.n_rows[~is_amb])
+        # fixed-length records without lens / flags
+        seq2, off2 = synth.make_reads(4, 50000, 150, seed=6)
+        pk2, _, _ = pp.pack_reads_host(seq2, off2)
+        a = pp.processQueriesPacked(pk2, fixed_len=150)
+        b = pp.processQueries(seq2, off2)
+        assert np.array_equal(a.branch, b.branch) and np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
+    finally:
+        db.close()
