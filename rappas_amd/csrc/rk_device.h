@@ -49,6 +49,10 @@ struct DbView {
     u32 convert_uo;
     u32 mono;  // every score >= T (all increments >= 0): first touch of a branch can be a max with the -inf marker
     u32 soa;  // large-tree (indexed) images: a row is u16 branch[len] followed by f32 score[len] (6 bytes per entry)
+    // mid-size trees (place_packed16w_kernel): the tree is cut into n_win windows of win_w branches; winspec[dense k-mer index] =
+    // (first window its row touches) | (last - first) << 4, 0 for absent k-mers; nullptr when the image is not windowed
+    const unsigned char *winspec;
+    u32 win_w, n_win;
 };
 
 struct PlaceArgs {
@@ -74,6 +78,7 @@ struct PlaceArgs {
     u32 s_stride;  // u32 words per read score vector in LDS
     u32 list_cap;  // u64 slots of the per-read hit list in LDS
     u32 n_pass;    // large-tree kernels: branch-range passes per read (1 unless the score vector exceeds one CU's LDS)
+    u32 main_cap, work_cap;  // windowed kernel: u32 slots of the per-read tagged item list / of the per-window work list
 };
 
 __device__ __forceinline__ u64 mix64(u64 x) {

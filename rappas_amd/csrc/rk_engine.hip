@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -24,6 +25,9 @@ using namespace rk;
 #ifndef RK_WG_MIN_MEAN_ROW
 #define RK_WG_MIN_MEAN_ROW 64.0     // ... for rows at least this long on average ...
 #define RK_WG_ALWAYS_BRANCHES 16000u  // ... or, whatever the rows, above this many branches
+#endif
+#ifndef RK_WINDOW_MIN_BRANCHES
+#define RK_WINDOW_MIN_BRANCHES 2800u  // below this the dense 32-lane geometry (>= 6 waves per CU) is ahead of the windowed kernel (scripts/tree_size_sweep.py)
 #endif
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
@@ -164,9 +168,9 @@ struct PinBuf {  // page-locked host staging, grow-only
 
 // memcpy split over a few host threads: one thread moves ~10 GB/s, the PCIe link five times that
 void parallel_copy(void *dst, const void *src, size_t bytes) {
-    const size_t min_part = 4u << 20;
+    const size_t min_part = 2u << 20;
     unsigned hw = std::thread::hardware_concurrency();
-    size_t parts = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 6u), bytes / min_part);
+    size_t parts = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 12u), bytes / min_part);
     if (parts <= 1) { if (bytes) memcpy(dst, src, bytes); return; }
     std::vector<std::thread> th;
     for (size_t i = 1; i < parts; i++) {
@@ -194,6 +198,32 @@ struct rk_workspace {
     }
 };
 
+// mid-size trees: the score vector of a read is held one window of W branches at a time (place_packed16w_kernel)
+struct WindowPlan {
+    uint32_t W = 0, n_win = 0, s_stride = 0, main_cap = 0, work_cap = 0;
+};
+
+// The dense 16-lane geometry keeps eight waves per CU up to 1 116 branches (choose_geometry); beyond that -- and up to the
+// 16 000 branches slot-offset images are built for -- the tree is cut into windows of <= 1 000 branches, at most 16 of them
+// (4-bit window ids in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
+static bool window_plan(uint32_t nb, WindowPlan &wp) {
+    if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
+    const uint32_t per_group_words = 160 * 1024 / 8 / 4 / 4;  // 1280 u32 words per read
+    uint32_t n_win = (nb + 895) / 896;
+    if (n_win > 16) n_win = 16;
+    wp.n_win = n_win;
+    wp.W = ((nb + n_win - 1) / n_win + 3) & ~3u;
+    wp.s_stride = wp.W + 4;
+    // the main list has to hold a whole read (C2-like reads: 145 row units on average, 250 at the tail); what is left goes to the
+    // per-window work list, so that a window is normally applied in one accumulate call (each call pays a pipeline fill)
+    const uint32_t avail = per_group_words - wp.s_stride;
+    uint32_t work = avail > 256 + 88 ? avail - 256 : 88;
+    if (work > 200) work = 200;
+    wp.work_cap = work & ~1u;
+    wp.main_cap = (avail - wp.work_cap) & ~1u;
+    return wp.main_cap >= 160;
+}
+
 struct rk_db {
     rk_db_info info{};
     uint32_t convert_uo = 0;
@@ -201,6 +231,9 @@ struct rk_db {
     void *d_table = nullptr;
     void *d_rows = nullptr;
     unsigned char *d_alpha = nullptr;  // table[256] | alts[320] | alt_count[16]
+    unsigned char *d_winspec = nullptr;  // [sigma^k] window span per k-mer (windowed images only)
+    bool windowed = false;
+    WindowPlan wp;
     uint32_t lanes_per_read = 0;       // 0 = auto
     uint32_t waves_per_block = 1;
     bool indexed = false;              // rows carry an index line (large trees, place_wg_kernel)
@@ -235,6 +268,7 @@ extern "C" void rk_db_destroy(rk_db *db) {
     if (db->d_table) (void)hipFree(db->d_table);
     if (db->d_rows) (void)hipFree(db->d_rows);
     if (db->d_alpha) (void)hipFree(db->d_alpha);
+    if (db->d_winspec) (void)hipFree(db->d_winspec);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     for (rk_workspace &w : db->ws) w.release();
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -305,6 +339,9 @@ static void finish_db(rk_db *db, const DbMeta &m, uint32_t mode, bool indexed, b
     db->view.T = m.thr_log10; db->view.P = m.thr; db->view.convert_uo = m.convert_uo;
     db->view.soa = indexed ? 1u : 0u;
     db->view.mono = mono ? 1u : 0u;
+    db->view.winspec = db->windowed ? db->d_winspec : nullptr;
+    db->view.win_w = db->windowed ? db->wp.W : 0u;
+    db->view.n_win = db->windowed ? db->wp.n_win : 0u;
 }
 
 static int check_launchable(const rk_db *db);
@@ -369,6 +406,9 @@ struct DbImage {
     uint64_t n_keys = 0, n_entries = 0, blob_bytes = 0, slots = 0, hash_mask = 0;
     std::vector<Entry> blob;
     std::vector<uint64_t> table;
+    bool windowed = false;              // place_packed16w_kernel can serve this image
+    WindowPlan wp;
+    std::vector<unsigned char> winspec;  // [sigma^k]
 };
 
 static int build_image(const rk_db_desc *d, DbImage &img) {
@@ -450,6 +490,12 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES && (mean_len >= RK_WG_MIN_MEAN_ROW || d->n_branches > RK_WG_ALWAYS_BRANCHES);
     img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
+    WindowPlan wp;
+    const bool want_windows = !indexed && window_plan(d->n_branches, wp);
+    std::vector<unsigned char> ws_by_key;  // first window | (last - first) << 4 of every row
+    if (want_windows) {
+        try { ws_by_key.assign(n_keys, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
+    }
     // slot-offset images: 128-byte units (ROW_UNIT = 16 entries), so a chunk of 16 entries is ONE aligned 128-byte request;
     // raw-id (indexed) images: 64-byte units
     const uint64_t unit_bytes = indexed ? 64 : ROW_UNIT * 8;
@@ -492,8 +538,11 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
                 uint64_t b = d->row_offsets[r], len = d->row_offsets[r + 1] - b;
                 Entry *ep = blob.data() + (desc[r] >> DESC_LEN_BITS);
                 if (indexed) { tmp.resize(len); ep = tmp.data(); }
+                uint32_t xmin = 0xFFFFu, xmax = 0;
                 for (uint64_t i = 0; i < len; i++) {
                     uint16_t x = d->branch_ids[b + i];
+                    xmin = x < xmin ? x : xmin;
+                    xmax = x > xmax ? x : xmax;
                     float v = d->scores[b + i];
                     if (x >= d->n_branches) { err = {1, r, x}; return; }
                     if (stamp[x] == (uint32_t)r) { err = {2, r, x}; return; }
@@ -503,6 +552,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
                     ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
                     ep[i].score = v;
                 }
+                if (want_windows) ws_by_key[r] = (unsigned char)((xmin / wp.W) | ((xmax / wp.W - xmin / wp.W) << 4));
                 if (indexed) {
                     std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
                     unsigned char *row = (unsigned char *)(blob.data() + (desc[r] >> DESC_LEN_BITS));
@@ -562,6 +612,13 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
 
     img.blob_bytes = blob_bytes;
     img.max_len = max_len;
+    // windows need the compact table (rows of <= 255 units) and 32-bit row offsets
+    if (want_windows && img.mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT) {
+        try { img.winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
+        for (uint64_t i = 0; i < n_keys; i++) img.winspec[order[i].first] = ws_by_key[order[i].second];
+        img.windowed = true;
+        img.wp = wp;
+    }
     return RK_OK;
 }
 
@@ -615,6 +672,12 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     DB_TRY(hipMalloc(&db->d_rows, blob_bytes));
     if (table_bytes) DB_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
     DB_TRY(hipMemcpy(db->d_rows, blob.data(), blob_bytes, hipMemcpyHostToDevice));
+    if (img.windowed) {
+        DB_TRY(hipMalloc((void **)&db->d_winspec, img.winspec.size()));
+        DB_TRY(hipMemcpy(db->d_winspec, img.winspec.data(), img.winspec.size(), hipMemcpyHostToDevice));
+        db->windowed = true;
+        db->wp = img.wp;
+    }
 #undef DB_TRY
     finish_db(db, meta, mode, indexed, img.mono, n_keys, n_entries, slots, hash_mask, table_bytes, blob_bytes, max_len);
     rc = check_launchable(db);  // a tree whose score vector no kernel geometry can hold is refused here, not at the first batch
@@ -834,6 +897,37 @@ template <int G>
 static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
     return db->info.bits_per_symbol == 2 ? launch_t<G, 2>(db, g, a, s) : launch_t<G, 5>(db, g, a, s);
 }
+// mid-size trees: the windowed kernel whenever the image carries window spans, nobody forced a lane-group width, the K best
+// of two windows fit one 16-lane row (keep_at_most <= 8) and the packed record fits one word per lane
+static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_per_read) {
+    static const bool off = getenv("RK_NO_WINDOW") != nullptr;  // developer knob: A/B against the dense kernels
+    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 8 && words_per_read <= 16;
+}
+
+static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
+    const WindowPlan &wp = db->wp;
+    a.s_stride = wp.s_stride; a.main_cap = wp.main_cap; a.work_cap = wp.work_cap; a.list_cap = wp.work_cap / 2;
+    const size_t lds_wave = (size_t)4 * (wp.s_stride + wp.main_cap + wp.work_cap) * 4;
+    uint32_t waves_cu = (uint32_t)(db->lds_per_cu / lds_wave);
+    if (waves_cu < 1) return fail(RK_ERR_UNSUPPORTED, "internal: windowed geometry does not fit the LDS");
+    if (waves_cu > 8) waves_cu = 8;  // two waves per SIMD: the kernel's register budget
+    const uint64_t n_tiles = (a.n_reads + 3) / 4;
+    uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
+    if (blocks > n_tiles) blocks = n_tiles;
+    if (!blocks) return RK_OK;
+    if (db->info.bits_per_symbol == 2) {
+        auto kern = place_packed16w_kernel<2, RK_RING, 9>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, a);
+    } else {
+        auto kern = place_packed16w_kernel<5, RK_RING, 9>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return RK_OK;
+}
+
 static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
     switch (g.G) {
     case 8: return launch_b<8>(db, g, a, s);
@@ -1009,6 +1103,13 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         m->kernel_name = buf;
         return m->kernel_name.c_str();
     }
+    if (use_windowed(db, 7, 16)) {
+        snprintf(buf, sizeof(buf), "place_packed16w_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches lds/wave=%zuB main=%u work=%u",
+                 db->info.bits_per_symbol, RK_RING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),
+                 db->wp.main_cap, db->wp.work_cap);
+        m->kernel_name = buf;
+        return m->kernel_name.c_str();
+    }
     if (choose_geometry(db, 7, g) != RK_OK) return "";
     PlaceArgs probe{};
     probe.words_per_read = 16;
@@ -1078,7 +1179,9 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
     a.o_nrows = d_out->n_rows; a.o_branch = d_out->branch; a.o_score = d_out->score; a.o_lwr = d_out->lwr; a.o_flags = d_out->flags;
     a.s_stride = use_wg ? wg.s_stride : g.s_stride;
     a.list_cap = use_wg ? wg.list_cap : g.list_cap;
-    rc = use_wg ? launch_wg(db, wg, a, s) : launch_place(db, g, a, s);
+    if (use_wg) rc = launch_wg(db, wg, a, s);
+    else if (use_windowed(db, p->keep_at_most, words_per_read)) rc = launch_windowed(db, a, s);
+    else rc = launch_place(db, g, a, s);
     if (rc) return rc;
     if (ascii) {
         AmbArgs m{};
@@ -1121,7 +1224,14 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     std::lock_guard<std::mutex> lock(db->host_mutex);  // the two workspaces belong to the db: one host call at a time
     HIP_TRY(hipSetDevice(db->info.device));
     const uint32_t K = p->keep_at_most;
-    const uint64_t max_chunk_reads = 1ull << 19, max_chunk_bytes = 128ull << 20;
+    // chunks of 2^18 reads: the kernel still fills the chip (2^16 tiles for 2 048 waves) and the part of a call that nothing
+    // overlaps -- the first chunk's upload, the last chunk's download and drain -- stays short
+    uint64_t max_chunk_reads = 1ull << 18;
+    if (const char *e = getenv("RK_CHUNK_READS")) {  // developer knob
+        const long v = atol(e);
+        if (v >= 1024) max_chunk_reads = (uint64_t)v;
+    }
+    const uint64_t max_chunk_bytes = 128ull << 20;
     for (rk_workspace &w : db->ws)
         if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     // Caller buffers from rk_host_alloc (or otherwise page-locked) are the DMA's source / target directly; pageable ones
@@ -1133,19 +1243,46 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     };
     const bool in_pinned = packed_in ? is_pinned(in.packed) : is_pinned(seq_ascii);
     const bool out_pinned = is_pinned(out->n_rows) && is_pinned(out->branch) && is_pinned(out->score) && is_pinned(out->lwr) && is_pinned(out->flags);
+    auto count_flags = [&](const uint32_t *fl, uint64_t m) {  // per-batch counters, taken chunk by chunk while the flags are cache-hot
+        for (uint64_t r = 0; r < m; r++) {
+            const uint32_t f = fl[r];
+            ct.reads++;
+            if (f & RK_FLAG_PLACED) ct.placed++; else ct.unplaced++;
+            if (f & RK_FLAG_BAD_CHAR) ct.bad_char++;
+            if (f & RK_FLAG_TOO_SHORT) ct.too_short++;
+            if (f & RK_FLAG_AMBIGUOUS) ct.ambiguous++;
+        }
+    };
     auto drain = [&](rk_workspace &w) {  // staged results of the workspace's last chunk -> the caller's arrays
         if (!w.pending) return;
         const uint64_t a0 = w.pend_r0, m = w.pend_n;
-        memcpy(out->n_rows + a0, w.h_nrows.p, m);
-        parallel_copy(out->branch + a0 * K, w.h_branch.p, m * K * 2);
-        parallel_copy(out->score + a0 * K, w.h_score.p, m * K * 4);
-        parallel_copy(out->lwr + a0 * K, w.h_lwr.p, m * K * 8);
-        memcpy(out->flags + a0, w.h_oflags.p, m * 4);
+        if (!out_pinned) {
+            // one set of threads for the five arrays, each thread a range of reads (103 bytes per read at K = 7)
+            unsigned hw = std::thread::hardware_concurrency();
+            const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1u, 12u), m / 16384));
+            auto part = [&](uint64_t lo, uint64_t hi) {
+                const uint64_t c = hi - lo;
+                memcpy(out->n_rows + a0 + lo, w.h_nrows.as<uint8_t>() + lo, c);
+                memcpy(out->branch + (a0 + lo) * K, w.h_branch.as<uint16_t>() + lo * K, c * K * 2);
+                memcpy(out->score + (a0 + lo) * K, w.h_score.as<float>() + lo * K, c * K * 4);
+                memcpy(out->lwr + (a0 + lo) * K, w.h_lwr.as<double>() + lo * K, c * K * 8);
+                memcpy(out->flags + a0 + lo, w.h_oflags.as<uint32_t>() + lo, c * 4);
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(part, m * t / T, m * (t + 1) / T);
+            part(0, m / T);
+            for (std::thread &x : th) x.join();
+        }
+        count_flags(out->flags + a0, m);
         w.pending = false;
     };
     uint64_t r0 = 0;
     unsigned chunk_no = 0;
     int status = RK_OK;
+    // developer knob: RK_HOST_TIMING=1 prints where the host thread of this call spent its time (stderr)
+    const bool timing = getenv("RK_HOST_TIMING") != nullptr;
+    double t_wait = 0, t_drain = 0, t_stage = 0, t_enq = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (r0 < n_reads && status == RK_OK) {
         uint64_t r1 = r0, max_len = 0;
         if (packed_in) {
@@ -1169,9 +1306,13 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         rk_workspace &w = db->ws[chunk_no & 1];
         hipStream_t s = w.stream;
         // the workspace was last used two chunks ago: its downloads must have landed before it is overwritten
+        double t0 = now();
         hipError_t he = hipStreamSynchronize(s);
         if (he != hipSuccess) { status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)); break; }
+        double t1 = now();
         drain(w);
+        double t2 = now();
+        t_wait += t1 - t0; t_drain += t2 - t1;
 #define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
 #define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
         WS_TRY(w.packed.reserve(n * wpr * 4));
@@ -1197,6 +1338,7 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             }
             WS_HIP(hipMemcpyAsync(w.off.p, w.h_off.p, (n + 1) * 8, hipMemcpyHostToDevice, s));
         }
+        double t3 = now();
         if (packed_in) {
             // packed records (+ lengths, flags): straight from page-locked caller memory, else through the staging buffer
             const size_t pb = n * wpr * 4, lb = in.lens ? n * 4 : 0, fb = in.flags ? n * 4 : 0;
@@ -1221,6 +1363,8 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             WS_TRY(rk_pack_reads_device(db, n, w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), wpr, w.packed.as<uint32_t>(),
                                         w.lens.as<uint32_t>(), w.flags.as<uint32_t>(), s));
         }
+        t_stage += now() - t2;
+        (void)t3;
         {
             rk_result dres{w.nrows.as<uint8_t>(), w.branch.as<uint16_t>(), w.score.as<float>(), w.lwr.as<double>(), w.oflags.as<uint32_t>()};
             const uint32_t *d_lens = (!packed_in || in.lens) ? w.lens.as<uint32_t>() : nullptr;
@@ -1234,6 +1378,7 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             WS_HIP(hipMemcpyAsync(out->score + r0 * K, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
             WS_HIP(hipMemcpyAsync(out->lwr + r0 * K, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
             WS_HIP(hipMemcpyAsync(out->flags + r0, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
+            w.pending = true; w.pend_r0 = r0; w.pend_n = n;  // (nothing to copy later, but the chunk's flags are still to be counted)
         } else {
             WS_TRY(w.h_nrows.reserve(n));
             WS_TRY(w.h_branch.reserve(n * K * 2));
@@ -1249,9 +1394,13 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         }
 #undef WS_TRY
 #undef WS_HIP
+        t_enq += now() - t2;
         r0 = r1;
         chunk_no++;
     }
+    if (timing)
+        fprintf(stderr, "%s: %u chunks; host thread: wait for stream %.1f ms, drain results %.1f ms, stage input %.1f ms, stage+enqueue %.1f ms\n",
+                who, chunk_no, t_wait * 1e3, t_drain * 1e3, t_stage * 1e3, t_enq * 1e3);
 done:
     for (rk_workspace &w : db->ws)
         if (w.stream) {
@@ -1261,14 +1410,6 @@ done:
             w.pending = false;
         }
     if (status != RK_OK) return status;
-    for (uint64_t r = 0; r < n_reads; r++) {
-        uint32_t f = out->flags[r];
-        ct.reads++;
-        if (f & RK_FLAG_PLACED) ct.placed++; else ct.unplaced++;
-        if (f & RK_FLAG_BAD_CHAR) ct.bad_char++;
-        if (f & RK_FLAG_TOO_SHORT) ct.too_short++;
-        if (f & RK_FLAG_AMBIGUOUS) ct.ambiguous++;
-    }
     if (counters) *counters = ct;
     return RK_OK;
 }

@@ -250,7 +250,7 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
         off_t eo = ok ? (off_t)(c.cur + 8 * li) : (off_t)0;
         if (RK_ABLATE & 16) eo = 0;  // timing-only: every row load reads the reserved "skip" entry
         const uint2 e = *(const uint2 *)(rows + eo);
-        br = e.x;
+        br = e.x;  // (raw: the windowed kernel rebases it at apply time, see accumulate_list)
         sc = __uint_as_float(e.y);
         c.cur += 8 * G;
     }
@@ -294,7 +294,8 @@ __device__ __forceinline__ void apply_slot(u32 *S, u32 sb, float sc, float QT, f
 }
 template <int G, int U, bool WIDE, bool SOA = false>
 __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list, int cnt, u32 li,
-                                                const unsigned char *rows, float QT, float T, u32 s_lo = 0, u32 s_win = 0xFFFFu) {
+                                                const unsigned char *rows, float QT, float T, u32 s_lo = 0, u32 s_win = 0xFFFFu,
+                                                u32 wlo4p4 = 4u, u32 w4 = 0xFFFFFFFFu) {
     Cursor<WIDE> c;
     c.h = -1; c.rem = 0; c.cur = 0; c.scur = 0;
     c.dn = list[0];
@@ -302,16 +303,21 @@ __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list,
     float sc[U];
 #pragma unroll
     for (int u = 0; u < U; u++) cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u], s_lo, s_win);
+    const bool win = !SOA && w4 != 0xFFFFFFFFu;  // windowed kernel, slot-offset image: rebase into the window S holds
+    auto slot_of = [&](u32 b) {
+        const u32 t = b - wlo4p4;
+        return win ? ((t < w4) ? t + 4u : 0u) : b;
+    };
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_slot(S, br[u], sc[u], QT, T);
+            apply_slot(S, slot_of(br[u]), sc[u], QT, T);
             cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u], s_lo, s_win);
         }
         if (!__any(c.h < cnt)) break;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) apply_slot(S, br[u], sc[u], QT, T);
+    for (int u = 0; u < U; u++) apply_slot(S, slot_of(br[u]), sc[u], QT, T);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,9 +400,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_resource(const DbView &db
     return __builtin_amdgcn_make_buffer_rsrc((void *)db.rows, (short)0, (int)(u32)db.rows_bytes, 0x00020000);
 }
 
-template <int G, int U, bool MONO>
+template <int G, int U, bool MONO, bool WIN = false>
 __device__ __forceinline__ void accumulate_units(u32 *S, const u32 *items, int wcnt, u32 li,
-                                                 __amdgpu_buffer_rsrc_t rs, float QT, float T) {
+                                                 __amdgpu_buffer_rsrc_t rs, float QT, float T, u32 wlo4p4 = 4u, u32 w4 = 0xFFFFFFFFu) {
     const u32 li8 = li * 8;
     const u32 my_unit = li >> 4;  // which 128-byte unit of the chunk this lane reads
     u32 sb[U], it[U];
@@ -406,8 +412,13 @@ __device__ __forceinline__ void accumulate_units(u32 *S, const u32 *items, int w
         if (G > 16) off = (my_unit <= (item & 7u)) ? (item & ~127u) + li8 : ITEM_FILLER;
         if (RK_ABLATE & 16) off = li8;
         const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
-        b = e.x;
+        b = e.x;  // (left untouched until its step: anything computed from it here would wait for the load and serialise the ring)
         v = __uint_as_float(e.y);
+    };
+    auto slot_of = [&](u32 b) {  // WIN: S holds one window of the tree -- slot offsets are rebased, everything outside goes to the scratch word
+        if (!WIN) return b;
+        const u32 t = b - wlo4p4;
+        return (t < w4) ? t + 4u : 0u;
     };
 #pragma unroll
     for (int u = 0; u < U; u++) issue(items[u], sb[u], sc[u]);
@@ -417,7 +428,7 @@ __device__ __forceinline__ void accumulate_units(u32 *S, const u32 *items, int w
     while (true) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            apply_slot<MONO>(S, sb[u], sc[u], QT, T);
+            apply_slot<MONO>(S, slot_of(sb[u]), sc[u], QT, T);
             issue(it[u], sb[u], sc[u]);
             it[u] = items[s0 + 2 * U + u];
         }
@@ -1264,6 +1275,248 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// place_packed16w_kernel: mid-size trees (about 1 000 .. 16 000 branches, rows short enough for the compact table).
+//
+// A dense score vector of 4 * n_branches bytes per read leaves a CU with 4-16 reads in flight and the kernel latency-bound
+// (94 Mreads/s at 3 999 branches against 340 at 999).  Here S holds one WINDOW of win_w branches at a time, so a read costs the
+// LDS of a 1 000-branch tree whatever the tree's size:
+//   probe + emit once: every 128-byte row unit becomes one item of the read's MAIN list, in k-mer order, tagged with the span
+//     of windows its row touches (winspec, one byte per k-mer next to the compact table: first window | (last - first) << 4);
+//   for every window: the items whose span contains it are compacted (order kept) into a WORK list and applied by
+//     accumulate_units with a window filter on the slot offsets (entries of other windows fall on the scratch word); then the
+//     usual select over the window, whose K best are merged into the K best so far.
+// Per-branch float32 order is untouched: a branch lives in exactly one window and its entries are applied in k-mer order.
+// A row that straddles windows is read once per window it touches (rows are mostly runs of neighbouring branches: rare).
+// Reads whose items do not fit the main list fall back to probing the read once per window (row descriptors + row cursor).
+// ------------------------------------------------------------------------------------------------
+template <int BITS, int U, int PU>
+__global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
+    constexpr int G = 16, NG = 4, TM = TM_COMPACT;
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = threadIdx.x >> 6;
+    const u32 waves_per_block = blockDim.x >> 6;
+    const u32 gi = lane / G, li = lane % G;
+    const u32 wave_words = NG * (a.s_stride + a.main_cap + a.work_cap);
+    u32 *wbase = lds + wave * wave_words;
+    u32 *S = wbase + gi * a.s_stride;
+    u32 *mainl = wbase + NG * a.s_stride + gi * a.main_cap;
+    u32 *work = wbase + NG * (a.s_stride + a.main_cap) + gi * a.work_cap;  // also the select phase's u64 scratch (work_cap even)
+    u64 *work64 = (u64 *)work;
+    const u32 nb = a.db.n_branches, k = a.db.k;
+    const u32 W = a.db.win_w, NWIN = a.db.n_win;
+    const float T = a.db.T;
+    const int K = (int)a.keep_at_most;  // <= 8 (the host picks the dense kernels otherwise)
+    const u64 gmask = (1ull << G) - 1;
+    const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
+    const int main_usable = (int)a.main_cap;
+    const int work_usable = (int)a.work_cap - 3 * U - 2;
+    const int cap_rows = (int)(a.work_cap / 2) - 1;
+    const u32 wpr = a.words_per_read;  // <= 16
+
+    for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
+    wave_lds_fence();
+
+    const u64 n_tiles = (a.n_reads + NG - 1) / NG;
+    const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
+    const u64 wave_count = (u64)gridDim.x * waves_per_block;
+
+    auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
+        const u64 r = tile * NG + gi;
+        have = tile < n_tiles && r < a.n_reads;
+        recw = 0; R = 0; fin = 0;
+        if (have) {
+            if (li < wpr) recw = a.packed[r * wpr + li];
+            R = a.lens ? a.lens[r] : a.fixed_len;
+            fin = a.flags_in ? a.flags_in[r] : 0u;
+        }
+    };
+    auto mer_count = [&](u32 R, u32 fin, bool have) -> u32 {
+        const u32 cap_syms = (wpr * 32u) / BITS;
+        R = R < cap_syms ? R : cap_syms;
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        return (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
+    };
+    auto fetch_batch = [&](u32 recw, u32 pos, u32 Q, u64 (&code)[PU], RawSlot (&raw)[PU], u32 (&wsr)[PU]) {
+        record_codes<BITS, PU>(recw, pos, li, k, Q, code);
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            raw[u] = lookup_fetch<BITS, TM>(a.db, code[u]);
+            wsr[u] = a.db.winspec[dense_index<BITS>(code[u], k)];
+        }
+    };
+    auto decode_batch = [&](const u64 (&code)[PU], const RawSlot (&raw)[PU], u32 pos, u32 Q, u64 (&desc)[PU]) {
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const u32 j = pos + u * G + li;
+            const u64 d = lookup_decode<BITS, TM>(a.db, raw[u], code[u]);
+            desc[u] = j < Q ? d : 0ull;
+        }
+    };
+    auto row_scan = [](u32 v) {  // inclusive prefix sum over the 16 lanes of a DPP row
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+        return v;
+    };
+    auto wave_max4 = [](int v) {  // largest value among the wave's four groups (v is group-uniform)
+        int m = __builtin_amdgcn_readlane(v, 0);
+        m = max(m, __builtin_amdgcn_readlane(v, 16));
+        m = max(m, __builtin_amdgcn_readlane(v, 32));
+        return max(m, __builtin_amdgcn_readlane(v, 48));
+    };
+
+    // prologue: the first tile's inputs (record word per lane, length, flags); later tiles' inputs are loaded one tile ahead.
+    // (Unlike place_packed16_kernel the table gathers are NOT carried across tiles: their ~70 live registers pushed the
+    // accumulate ring into scratch spills, which serialise it; with 3-16 window passes per tile the probe latency is small change.)
+    u32 c_recw, c_R, c_fin;
+    bool c_have;
+    load_tile(wave_global, c_recw, c_R, c_fin, c_have);
+
+    for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const u64 r = tile * NG + gi;
+        const bool have = c_have;
+        const u32 fin = c_fin;
+        u32 R = c_R;
+        {
+            const u32 cap_syms = (wpr * 32u) / BITS;
+            R = R < cap_syms ? R : cap_syms;
+        }
+        u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        if (R < k) flags |= RK_FLAG_TOO_SHORT;
+        const u32 Q = mer_count(c_R, fin, have);
+        const float QT = (float)(int)Q * T;
+
+        // ---- emit: every row unit of the read -> one tagged item of the main list, k-mer order ----
+        int mcnt = 0;
+        bool overflow = false;  // wave-uniform: some read of the tile does not fit its main list
+        auto emit_tagged = [&](const u64 (&desc)[PU], const u32 (&ws)[PU], bool more) {
+            u32 nch[PU], excl[PU];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                nch[u] = (((u32)desc[u] & DESC_LEN_MASK) + G - 1) >> 4;  // <= 255 units (compact table)
+                const u32 incl = row_scan(nch[u]);
+                excl[u] = (u32)total + incl - nch[u];
+                total += (int)row_bcast32<15>(incl);
+            }
+            if (__any(more && mcnt + total > main_usable)) { overflow = true; return; }
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const u32 sp = ws[u] >> 4;
+                const u32 tag = (ws[u] & 15u) | ((sp < 7u ? sp : 7u) << 4);
+                const u32 rb = (u32)(desc[u] >> DESC_LEN_BITS) * 8u;
+                const int base = mcnt + (int)excl[u];
+                if (nch[u] > 0) mainl[base] = rb | tag;
+                if (nch[u] > 1) mainl[base + 1] = (rb + 128u) | tag;
+                for (u32 c = 2; __any(c < nch[u]); c++)
+                    if (c < nch[u]) mainl[base + (int)c] = (rb + c * 128u) | tag;
+            }
+            mcnt += total;
+        };
+        for (u32 pos = 0; !overflow && __any(pos < Q); pos += PU * G) {
+            u64 code[PU], desc[PU];
+            RawSlot raw[PU];
+            u32 ws[PU];
+            fetch_batch(c_recw, pos, Q, code, raw, ws);
+            __builtin_amdgcn_sched_barrier(0);
+            decode_batch(code, raw, pos, Q, desc);
+            emit_tagged(desc, ws, pos < Q);
+        }
+        wave_lds_fence();
+        // next tile's inputs: in flight during this tile's window passes
+        u32 n_recw, n_R, n_fin;
+        bool n_have;
+        load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
+
+        u64 acc_key = 0;  // lane r < K: rank-r key over the windows done so far (low 16 bits: 0xFFFF - tree branch id)
+        for (u32 w = 0; w < NWIN; w++) {
+            const u32 wlo = w * W;
+            const u32 win_n = nb - wlo < W ? nb - wlo : W;
+            const u32 wlo4p4 = wlo * 4u + 4u, w4 = win_n * 4u;
+            if (!overflow) {
+                // ---- this window's items, order kept, then applied ----
+                int wc = 0;
+                auto flushw = [&]() {
+                    const int wcnt = wave_max4(wc);
+                    for (int i = wc + (int)li; i < wcnt + 2 * U; i += G) work[i] = ITEM_FILLER;
+                    wave_lds_fence();
+                    if (!(RK_ABLATE & 512)) {
+                        if (a.db.mono) accumulate_units<G, U, true, true>(S, work, wcnt, li, rows_rs, QT, T, wlo4p4, w4);
+                        else accumulate_units<G, U, false, true>(S, work, wcnt, li, rows_rs, QT, T, wlo4p4, w4);
+                    }
+                    wave_lds_fence();
+                    wc = 0;
+                };
+                const int mx = (RK_ABLATE & 2048) ? 0 : wave_max4(mcnt);  // (timing only: no compaction, no accumulate)
+                for (int base = 0; base < mx; base += G) {
+                    const int i = base + (int)li;
+                    const u32 it = i < mcnt ? mainl[i] : 0u;
+                    const u32 f = it & 15u, sp = (it >> 4) & 7u;
+                    const u32 l = sp == 7u ? 15u : f + sp;
+                    const bool sel = i < mcnt && f <= w && w <= l;
+                    const u32 incl = row_scan(sel ? 1u : 0u);
+                    if (__any(wc + G > work_usable)) flushw();
+                    if (sel) work[wc + (int)incl - 1] = it & ~127u;
+                    wc += (int)row_bcast32<15>(incl);
+                }
+                if (__any(wc > 0)) flushw();
+            } else {
+                // ---- fallback: probe the read again for this window; rows that touch it go through the row cursor ----
+                int rc = 0;
+                auto flush_rows = [&]() {
+                    if (li == 0) work64[rc] = 0ull;  // sentinel: an empty row ends the cursor
+                    wave_lds_fence();
+                    if (__any(rc > 0)) accumulate_list<G, U, false>(S, nb, work64, rc, li, a.db.rows, QT, T, 0u, 0xFFFFu, wlo4p4, w4);
+                    wave_lds_fence();
+                    rc = 0;
+                };
+                for (u32 pos = 0; __any(pos < Q); pos += PU * G) {
+                    u64 code[PU], desc[PU];
+                    RawSlot raw[PU];
+                    u32 ws[PU];
+                    fetch_batch(c_recw, pos, Q, code, raw, ws);
+                    __builtin_amdgcn_sched_barrier(0);
+                    decode_batch(code, raw, pos, Q, desc);
+#pragma unroll
+                    for (int u = 0; u < PU; u++) {
+                        const u32 f = ws[u] & 15u, l = f + (ws[u] >> 4);
+                        const bool hit = ((u32)desc[u] & DESC_LEN_MASK) != 0 && f <= w && w <= l;
+                        if (__any(rc + G > cap_rows)) flush_rows();
+                        const u64 sub = (__ballot(hit) >> (gi * G)) & gmask;
+                        if (hit) work64[rc + __builtin_popcountll(sub & ((1ull << li) - 1))] = desc[u];
+                        rc += __builtin_popcountll(sub);
+                    }
+                }
+                flush_rows();
+            }
+            // ---- select over the window, merged into the K best so far ----
+            u64 win_key = 0;
+            if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key);  // (timing only)
+            wave_lds_fence();
+            if (win_key != 0ull) win_key -= (u64)wlo;  // window-relative branch -> tree id (low 16 bits hold 0xFFFF - branch)
+            const u64 moved = ((u64)row_ror32<8>((u32)(win_key >> 32)) << 32) | row_ror32<8>((u32)win_key);  // lane r -> lane r + 8
+            const u64 comb = li < 8 ? acc_key : moved;
+            const int rank = RankAbove<G, G - 1>::run(comb, li);
+            work64[li] = 0ull;
+            wave_lds_fence();
+            if (comb != 0ull && rank < K) work64[rank] = comb;
+            wave_lds_fence();
+            acc_key = (int)li < K ? work64[li] : 0ull;
+            wave_lds_fence();
+        }
+        const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+        const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+        if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
+        c_recw = n_recw; c_R = n_R; c_fin = n_fin; c_have = n_have;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // large trees: one WORKGROUP per read (place_wg_kernel)
 //
 // When S[n_branches] takes most of a CU's LDS (C5: 19 999 branches = 80 KB) a single wave per read leaves 2 waves
@@ -1947,18 +2200,23 @@ __global__ void __launch_bounds__(256) pack_reads_kernel(const unsigned char *as
         // symbols overlapping bits [32w, 32w+32)
         const u32 s_lo = (32u * w) / BITS;
         u32 s_hi = (32u * w + 31u) / BITS;  // inclusive
-        u64 acc = 0;                        // bits relative to 32w - (BITS-1) .. keep simple with signed shifts
+        // 32-bit arithmetic on purpose.  The first version accumulated in 64 bits (`acc |= (u64)st >> (-shift)` for the symbol
+        // that straddles the word's lower edge); on gfx950 that form -- hipcc emits v_lshlrev_b64 / v_lshrrev_b64 back to back on
+        // the same register pair -- lost the straddling symbol's bits in a few percent of the waves of every workgroup after the
+        // first 256, differently from run to run (scripts/ubench/pack_repro.hip reproduces it in plain HIP; 5-bit records only:
+        // 2-bit symbols never straddle).  Small batches never showed it, which is why it survived round 1.
+        u32 acc = 0;
+        const u32 wbase = 32u * w;
         for (u32 sidx = s_lo; sidx <= s_hi; sidx++) {
             if (sidx >= R) break;
             u32 c = tab[ascii[o0 + sidx]];
             u32 st = c;
             if (c == 0xFF) { fl |= RK_FLAG_BAD_CHAR; st = 0; }
             else if (c & 0x80) { fl |= RK_FLAG_AMBIGUOUS; st = 0; }
-            int shift = (int)(sidx * BITS) - (int)(32u * w);
-            if (shift >= 0) acc |= (u64)st << shift;
-            else acc |= (u64)st >> (-shift);
+            const u32 lo = sidx * BITS;
+            acc |= lo >= wbase ? st << (lo - wbase) : st >> (wbase - lo);
         }
-        packed[t] = (u32)acc;
+        packed[t] = acc;
         if (fl) atomicOr(&flags[r], fl);
     }
 }

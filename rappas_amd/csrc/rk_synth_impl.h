@@ -155,6 +155,12 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     sp.surv = surv.data();
     sp.surv_n = (uint32_t)surv.size();
 
+    WindowPlan wp;
+    const bool want_windows = window_plan(d->n_branches, wp);  // (used only when the image turns out not to be an indexed one)
+    std::vector<unsigned char> winspec;  // [space] first window | (last - first) << 4 of every row (rows are branch runs)
+    if (want_windows) {
+        try { winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create_synth: host OOM"); }
+    }
     // ---- pass 1 (host): which codes carry a row and how long it is; rows are laid out in dense order ----
     std::vector<u64> dense, lens32;  // lens32: row length per present key (u64 to share the prefix pass below)
     {
@@ -170,8 +176,13 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
                     for (uint64_t c = lo; c < hi; c++) {
                         const uint64_t h0 = synth_h0(sp.seed, c);
                         if ((h0 >> 32) >= sp.key_thresh) continue;
+                        const u32 len = synth_len(sp, h0);
                         dpart[t].push_back(c);
-                        lpart[t].push_back(synth_len(sp, h0));
+                        lpart[t].push_back(len);
+                        if (want_windows) {
+                            const u32 b0 = synth_b0(sp, h0, len), f = b0 / wp.W, l = (b0 + len - 1) / wp.W;
+                            winspec[c] = (unsigned char)(f | ((l - f) << 4));
+                        }
                     }
                 } catch (const std::bad_alloc &) { oom = true; }
             };
@@ -249,6 +260,12 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     SY_TRY(hipMalloc(&db->d_rows, blob_bytes));
     if (table_bytes) SY_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
     SY_TRY(hipMemset(db->d_rows, indexed ? 0xFF : 0, unit_bytes));  // unit 0: the reserved "skip" / scratch pattern
+    if (want_windows && !indexed && mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT) {
+        SY_TRY(hipMalloc((void **)&db->d_winspec, winspec.size()));
+        SY_TRY(hipMemcpy(db->d_winspec, winspec.data(), winspec.size(), hipMemcpyHostToDevice));
+        db->windowed = true;
+        db->wp = wp;
+    }
     if (n_keys) {
         SY_TRY(hipMalloc(&d_dense.p, n_keys * 8));
         SY_TRY(hipMalloc(&d_desc.p, n_keys * 8));

@@ -585,3 +585,68 @@ def test_packed_host_entry_equals_the_ascii_entry(c2_small, amb):
         assert np.array_equal(a.branch, b.branch) and np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
     finally:
         db.close()
+
+
+# ---- mid-size trees: the windowed kernel (score vector held one window of <= 1000 branches at a time) ----
+def _scatter_rows(sdb, seed):
+    """rows whose branches are scattered over the whole tree instead of a run of neighbours: every row touches many windows"""
+    rng = np.random.default_rng(seed)
+    br = sdb.branch_ids.copy()
+    for r in range(sdb.n_keys):
+        a, b = int(sdb.row_offsets[r]), int(sdb.row_offsets[r + 1])
+        br[a:b] = rng.choice(sdb.n_branches - 1, size=b - a, replace=False) + 1
+    return synth.SynthDB(sdb.alphabet, sdb.k, sdb.n_branches, sdb.thr, sdb.thr_log10, sdb.key_codes, sdb.row_offsets, br, sdb.scores, sdb.seed)
+
+
+@pytest.mark.parametrize("n_branches", [2801, 3999, 7999, 15999])
+@pytest.mark.parametrize("amb", ["mean", "skip"])
+def test_mid_size_trees_take_the_windowed_kernel(n_branches, amb):
+    sdb = synth.make_db(4, 8, n_branches, 40000, 520000, seed=n_branches)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_reads(4, 3000, 150, seed=2, amb_rate=0.001, bad_rate=0.002, var_len=40)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_packed16w_kernel" in db.kernel_name(), db.kernel_name()
+    db.close()
+    _, _, st = run_case(sdb, odb, seq, off, "direct", 0, amb)
+    assert st["placed"] > 2500
+
+
+def test_windowed_kernel_rows_scattered_over_all_windows():
+    sdb = _scatter_rows(synth.make_db(4, 7, 5000, 12000, 150000, seed=9), seed=10)
+    seq, off = synth.make_reads(4, 1500, 150, seed=3, amb_rate=0.001)
+    _, _, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, "mean")
+    assert st["placed"] == 1500
+
+
+def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window():
+    """250-bp reads against a database where every k-mer has a row of ~40 entries: ~700 row units per read, more than the main
+    list holds -> the per-window probe with the row cursor"""
+    sdb = synth.make_db(4, 6, 6001, 4096, 160000, seed=4)
+    seq, off = synth.make_reads(4, 1200, 250, seed=8, var_len=120)
+    _, _, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, "mean")
+    assert st["placed"] == 1200
+
+
+def test_windowed_kernel_protein_and_keep_at_most():
+    sdb = synth.make_db(20, 3, 3100, 6000, 60000, seed=6)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_reads(20, 1500, 100, seed=1, amb_rate=0.002, var_len=30)
+    for K in (1, 8, 9, 16):  # 9 and 16 do not fit the window merge: the dense kernels serve them
+        run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0001)
+
+
+def test_windowed_and_dense_kernels_agree(monkeypatch):
+    sdb = synth.make_db(4, 8, 4500, 40000, 520000, seed=77)
+    seq, off = synth.make_reads(4, 20000, 150, seed=5)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    try:
+        pp = ra.PlacementProcess(db)
+        a = pp.processQueries(seq, off)
+        db.set_lanes_per_read(32)  # an explicit lane-group width selects the dense kernel
+        b = pp.processQueries(seq, off)
+        assert "place_packed_kernel" in db.kernel_name()
+        for f in ("n_rows", "branch", "flags", "lwr"):
+            assert np.array_equal(getattr(a, f), getattr(b, f))
+        assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
+    finally:
+        db.close()
