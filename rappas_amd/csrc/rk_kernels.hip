@@ -238,11 +238,7 @@ __device__ __forceinline__ void cursor_issue(Cursor<WIDE> &c, const u64 *list, i
     if (SOA) {
         const off_t bo = ok ? (off_t)(c.cur + 2 * li) : (off_t)0;
         const off_t so = ok ? (off_t)(c.scur + 4 * li) : (off_t)0;
-        const u32 b16 = *(const unsigned short *)(rows + bo);
-        // raw id -> slot offset inside the score-vector window [s_lo, s_lo + s_win) the caller holds in LDS (the whole tree unless
-        // it exceeds the LDS); 0xFFFF = padding / reserved line 0 and ids outside the window go to the scratch word
-        const u32 xw = b16 - s_lo;
-        br = (xw < s_win) ? (xw + 1u) * 4u : 0u;
+        br = *(const unsigned short *)(rows + bo);  // raw id, turned into a slot offset at apply time (accumulate_list)
         sc = *(const float *)(rows + so);
         c.cur += 2 * G;
         c.scur += 4 * G;
@@ -303,8 +299,17 @@ __device__ __forceinline__ void accumulate_list(u32 *S, u32 nb, const u64 *list,
     float sc[U];
 #pragma unroll
     for (int u = 0; u < U; u++) cursor_issue<G, WIDE, SOA>(c, list, cnt, li, (int)li, rows, br[u], sc[u], s_lo, s_win);
-    const bool win = !SOA && w4 != 0xFFFFFFFFu;  // windowed kernel, slot-offset image: rebase into the window S holds
+    // what a loaded entry's first word means is settled only when its step comes (anything computed from it at load time would
+    // wait for the load and serialise the ring):
+    //   large-tree images: a raw branch id -> slot offset inside the window [s_lo, s_lo + s_win) of the tree S holds (the whole
+    //     tree unless it exceeds the LDS); 0xFFFF = padding / reserved line 0 and ids outside the window go to the scratch word;
+    //   slot-offset images: already a slot offset; the windowed kernel rebases it into its window.
+    const bool win = !SOA && w4 != 0xFFFFFFFFu;
     auto slot_of = [&](u32 b) {
+        if (SOA) {
+            const u32 xw = b - s_lo;
+            return (xw < s_win) ? (xw + 1u) * 4u : 0u;
+        }
         const u32 t = b - wlo4p4;
         return win ? ((t < w4) ? t + 4u : 0u) : b;
     };
@@ -688,6 +693,93 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 g
     RK_STAMP(9);
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
+    return num;
+}
+
+// ---- the fast select cut in two, for kernels that see the score vector one window at a time (place_packed16w_kernel):
+//      per window the scan feeds a lane's three best (score, global slot) pairs and resets S; the K rounds run once at the end ----
+struct Top3 {
+    float s0, s1, s2, s3;  // three best scores of the lane, and the best one it had to drop
+    u32 i0, i1, i2;        // their slots (tree branch id + 1)
+};
+__device__ __forceinline__ void top3_clear(Top3 &t) {
+    t.s0 = t.s1 = t.s2 = t.s3 = -INFINITY;
+    t.i0 = t.i1 = t.i2 = 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void top3_feed(Top3 &t, float v, u32 idx) {  // (one select per statement: see select_topk)
+    const bool g0 = v > t.s0, g1 = v > t.s1, g2 = v > t.s2;
+    const u32 t2 = g2 ? idx : t.i2;
+    t.i2 = g1 ? t.i1 : t2;
+    const u32 t1 = g1 ? idx : t.i1;
+    t.i1 = g0 ? t.i0 : t1;
+    t.i0 = g0 ? idx : t.i0;
+    t.s3 = __builtin_amdgcn_fmed3f(v, t.s2, t.s3);
+    t.s2 = __builtin_amdgcn_fmed3f(v, t.s1, t.s2);
+    t.s1 = __builtin_amdgcn_fmed3f(v, t.s0, t.s1);
+    t.s0 = g0 ? v : t.s0;
+}
+// scans the n_branches + 1 slots of S (slot 0 = scratch, slot i = branch slot_base + i - 1 of the tree), then resets them
+template <int G>
+__device__ __forceinline__ void top3_scan_reset(u32 *S, u32 n_branches, u32 li, u32 slot_base, Top3 &t) {
+    if (li == 0) S[0] = S_UNTOUCHED;
+    wave_lds_fence();
+    const u32 nb = n_branches + 1;
+    const uint4 *S4 = (const uint4 *)S;
+    uint4 *S4w = (uint4 *)S;
+    const u32 n4 = (nb + 3) / 4, n4_full = nb / 4;
+    if (li < n4_full) {
+        uint4 cur = S4[li];
+        for (u32 q = li; q < n4_full; q += G) {
+            const uint4 v4 = cur;
+            if (q + G < n4_full) cur = S4[q + G];
+            const u32 i = slot_base + 4 * q;
+            top3_feed(t, __uint_as_float(v4.x), i);
+            top3_feed(t, __uint_as_float(v4.y), i + 1);
+            top3_feed(t, __uint_as_float(v4.z), i + 2);
+            top3_feed(t, __uint_as_float(v4.w), i + 3);
+        }
+    }
+    if ((nb & 3u) && (n4_full % G) == li) {
+        const uint4 v4 = S4[n4_full];
+        const u32 i = 4 * n4_full;
+        top3_feed(t, i < nb ? __uint_as_float(v4.x) : -INFINITY, slot_base + i);
+        top3_feed(t, i + 1 < nb ? __uint_as_float(v4.y) : -INFINITY, slot_base + i + 1);
+        top3_feed(t, i + 2 < nb ? __uint_as_float(v4.z) : -INFINITY, slot_base + i + 2);
+        top3_feed(t, i + 3 < nb ? __uint_as_float(v4.w) : -INFINITY, slot_base + i + 3);
+    }
+    wave_lds_fence();
+    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
+    for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
+}
+// K rounds over the lane heads (as in select_topk); returns numBest, the rank-r key in lane r, and whether a dropped entry
+// could belong to the answer (then the caller has to redo the read with the exact select)
+template <int G>
+__device__ __forceinline__ int top3_rounds(const Top3 &t, int K, u32 li, u32 gi, u64 &win_key, bool &doubt) {
+    constexpr u32 ORD_NEG_INF = 0x007FFFFFu;
+    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    u32 o0 = ord_f32(t.s0), o1 = ord_f32(t.s1), o2 = ord_f32(t.s2);
+    u32 i0 = t.i0, i1 = t.i1, i2 = t.i2;
+    u32 win_o = 0, win_i = 0, last = ORD_NEG_INF;
+    int num = 0;
+    for (int r = 0; r < K; r++) {
+        const u32 m = group_max_u32<G>(o0);
+        const bool valid = m != ORD_NEG_INF;
+        const bool head = valid && o0 == m;
+        const u32 w = group_max_u32<G>(head ? ~i0 : 0u);
+        const bool pop = head && ~i0 == w;
+        const bool mine = (int)li == r && valid;
+        win_o = mine ? m : win_o;
+        win_i = mine ? ~w : win_i;
+        num += valid ? 1 : 0;
+        last = valid ? m : last;
+        o0 = pop ? o1 : o0; i0 = pop ? i1 : i0;
+        o1 = pop ? o2 : o1; i1 = pop ? i2 : i1;
+        o2 = pop ? ORD_NEG_INF : o2; i2 = pop ? 0xFFFFFFFFu : i2;
+    }
+    const u32 o3 = ord_f32(t.s3);
+    const bool d = (num == K) ? (o3 >= last) : (o3 != ORD_NEG_INF);
+    doubt = ((__ballot(d) >> (gi * G)) & gmask) != 0;
+    win_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
     return num;
 }
 
@@ -1433,8 +1525,8 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         bool n_have;
         load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
 
-        u64 acc_key = 0;  // lane r < K: rank-r key over the windows done so far (low 16 bits: 0xFFFF - tree branch id)
-        for (u32 w = 0; w < NWIN; w++) {
+        // this window's entries of the read applied to S (window w holds the branches [w * W, w * W + win_n))
+        auto window_accumulate = [&](u32 w) {
             const u32 wlo = w * W;
             const u32 win_n = nb - wlo < W ? nb - wlo : W;
             const u32 wlo4p4 = wlo * 4u + 4u, w4 = win_n * 4u;
@@ -1494,6 +1586,29 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 }
                 flush_rows();
             }
+        };
+        // fast pass: every window is scanned into the lanes' three best entries and reset; the K rounds run once, over the whole
+        // tree.  If an entry a lane had to drop could still belong to the answer (rare: a lane would need >= 4 of the K best),
+        // the tile is redone with the exact select of every window and a merge of the windows' K best.
+        u64 acc_key = 0;  // lane r < K: rank-r key (low 16 bits: 0xFFFF - tree branch id)
+        bool doubt = false;
+        {
+            Top3 t3;
+            top3_clear(t3);
+            for (u32 w = 0; w < NWIN; w++) {
+                window_accumulate(w);
+                const u32 wlo = w * W;
+                top3_scan_reset<G>(S, nb - wlo < W ? nb - wlo : W, li, wlo, t3);
+                wave_lds_fence();
+            }
+            top3_rounds<G>(t3, K, li, gi, acc_key, doubt);
+        }
+        if (__any(doubt)) {
+            acc_key = 0;
+            for (u32 w = 0; w < NWIN; w++) {
+                window_accumulate(w);
+                const u32 wlo = w * W;
+                const u32 win_n = nb - wlo < W ? nb - wlo : W;
             // ---- select over the window, merged into the K best so far ----
             u64 win_key = 0;
             if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key);  // (timing only)
@@ -1508,6 +1623,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
             wave_lds_fence();
             acc_key = (int)li < K ? work64[li] : 0ull;
             wave_lds_fence();
+            }
         }
         const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
