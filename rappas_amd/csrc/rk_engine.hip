@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -241,7 +243,7 @@ struct rk_db {
     size_t lds_per_cu = 160 * 1024;
     hipStream_t stream = nullptr;      // spare stream
     std::mutex host_mutex;             // rk_place_batch (host path) owns the workspaces below
-    rk_workspace ws[2];                // device buffers + stream per in-flight chunk (grow-only)
+    rk_workspace ws[3];                // device buffers + stream per in-flight chunk (grow-only)
     std::string kernel_name;
 };
 
@@ -1283,6 +1285,55 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     const bool timing = getenv("RK_HOST_TIMING") != nullptr;
     double t_wait = 0, t_drain = 0, t_stage = 0, t_enq = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // Three workspaces in flight.  This thread stages and enqueues chunk c while a second host thread waits for the stream
+    // of the oldest chunk and moves its results into the caller's arrays: staging, the GPU's work and the result copies of
+    // three different chunks overlap (one host thread doing both by turns kept the GPU waiting: 1.6e8 reads/s on C2).
+    constexpr unsigned NWS = 3;
+    std::mutex qm;
+    std::condition_variable qcv;
+    std::deque<unsigned> submitted;   // workspace indices in submission order
+    bool ws_busy[NWS] = {false, false, false};
+    bool closing = false;
+    int drain_status = RK_OK;
+    std::string drain_msg;
+    const int device = db->info.device;
+    std::thread drainer([&]() {
+        (void)hipSetDevice(device);
+        while (true) {
+            unsigned wi;
+            {
+                std::unique_lock<std::mutex> lk(qm);
+                qcv.wait(lk, [&]() { return !submitted.empty() || closing; });
+                if (submitted.empty()) return;
+                wi = submitted.front();
+                submitted.pop_front();
+            }
+            rk_workspace &w = db->ws[wi];
+            const double t0 = now();
+            const hipError_t he = hipStreamSynchronize(w.stream);
+            const double t1 = now();
+            if (he != hipSuccess) {
+                std::lock_guard<std::mutex> lk(qm);
+                if (drain_status == RK_OK) { drain_status = RK_ERR_HIP; drain_msg = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(he); }
+                w.pending = false;
+            } else {
+                bool ok;
+                { std::lock_guard<std::mutex> lk(qm); ok = drain_status == RK_OK; }
+                if (ok) drain(w); else w.pending = false;
+            }
+            t_wait += t1 - t0; t_drain += now() - t1;
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                ws_busy[wi] = false;
+            }
+            qcv.notify_all();
+        }
+    });
+    auto finish = [&]() {  // every submitted chunk drained, the thread joined
+        { std::lock_guard<std::mutex> lk(qm); closing = true; }
+        qcv.notify_all();
+        drainer.join();
+    };
     while (r0 < n_reads && status == RK_OK) {
         uint64_t r1 = r0, max_len = 0;
         if (packed_in) {
@@ -1303,16 +1354,16 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         if (packed_in && in.flags && seq_ascii && seq_off)
             for (uint64_t r = r0; r < r1 && !need_ascii; r++) need_ascii = (in.flags[r] & RK_FLAG_AMBIGUOUS) != 0;
         const uint64_t nbytes = need_ascii ? seq_off[r1] - seq_off[r0] : 0;
-        rk_workspace &w = db->ws[chunk_no & 1];
+        const unsigned wi = chunk_no % NWS;
+        rk_workspace &w = db->ws[wi];
         hipStream_t s = w.stream;
-        // the workspace was last used two chunks ago: its downloads must have landed before it is overwritten
-        double t0 = now();
-        hipError_t he = hipStreamSynchronize(s);
-        if (he != hipSuccess) { status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)); break; }
-        double t1 = now();
-        drain(w);
+        // the workspace was last used three chunks ago: its results must have left the staging buffers before it is overwritten
+        {
+            std::unique_lock<std::mutex> lk(qm);
+            qcv.wait(lk, [&]() { return !ws_busy[wi]; });
+            if (drain_status != RK_OK) { status = fail(drain_status, "%s", drain_msg.c_str()); break; }
+        }
         double t2 = now();
-        t_wait += t1 - t0; t_drain += t2 - t1;
 #define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
 #define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
         WS_TRY(w.packed.reserve(n * wpr * 4));
@@ -1378,7 +1429,6 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             WS_HIP(hipMemcpyAsync(out->score + r0 * K, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
             WS_HIP(hipMemcpyAsync(out->lwr + r0 * K, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
             WS_HIP(hipMemcpyAsync(out->flags + r0, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
-            w.pending = true; w.pend_r0 = r0; w.pend_n = n;  // (nothing to copy later, but the chunk's flags are still to be counted)
         } else {
             WS_TRY(w.h_nrows.reserve(n));
             WS_TRY(w.h_branch.reserve(n * K * 2));
@@ -1390,25 +1440,30 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             WS_HIP(hipMemcpyAsync(w.h_score.p, w.score.p, n * K * 4, hipMemcpyDeviceToHost, s));
             WS_HIP(hipMemcpyAsync(w.h_lwr.p, w.lwr.p, n * K * 8, hipMemcpyDeviceToHost, s));
             WS_HIP(hipMemcpyAsync(w.h_oflags.p, w.oflags.p, n * 4, hipMemcpyDeviceToHost, s));
-            w.pending = true; w.pend_r0 = r0; w.pend_n = n;
         }
 #undef WS_TRY
 #undef WS_HIP
+        w.pending = true; w.pend_r0 = r0; w.pend_n = n;  // (page-locked caller arrays: nothing to copy, the flags are still counted)
+        {
+            std::lock_guard<std::mutex> lk(qm);
+            ws_busy[wi] = true;
+            submitted.push_back(wi);
+        }
+        qcv.notify_all();
         t_enq += now() - t2;
         r0 = r1;
         chunk_no++;
     }
-    if (timing)
-        fprintf(stderr, "%s: %u chunks; host thread: wait for stream %.1f ms, drain results %.1f ms, stage input %.1f ms, stage+enqueue %.1f ms\n",
-                who, chunk_no, t_wait * 1e3, t_drain * 1e3, t_stage * 1e3, t_enq * 1e3);
 done:
-    for (rk_workspace &w : db->ws)
-        if (w.stream) {
-            hipError_t he = hipStreamSynchronize(w.stream);
-            if (he != hipSuccess && status == RK_OK) status = fail(RK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he));
-            if (status == RK_OK) drain(w);
-            w.pending = false;
-        }
+    finish();
+    for (rk_workspace &w : db->ws) {  // (after an error some streams may still hold work of a half-enqueued chunk)
+        if (w.stream && status != RK_OK) (void)hipStreamSynchronize(w.stream);
+        w.pending = false;
+    }
+    if (timing)
+        fprintf(stderr, "%s: %u chunks; submit thread: stage input %.1f ms, stage+enqueue %.1f ms; drain thread: wait for stream %.1f ms, move results %.1f ms\n",
+                who, chunk_no, t_stage * 1e3, t_enq * 1e3, t_wait * 1e3, t_drain * 1e3);
+    if (status == RK_OK && drain_status != RK_OK) status = fail(drain_status, "%s", drain_msg.c_str());
     if (status != RK_OK) return status;
     if (counters) *counters = ct;
     return RK_OK;

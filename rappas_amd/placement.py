@@ -31,6 +31,18 @@ class Placements:
     counters: dict
 
 
+def host_alloc(shape, dtype):
+    """numpy array in page-locked host memory (rk_host_alloc): buffers the DMA reads / writes directly, no staging copies in
+    rk_place_batch / rk_place_batch_packed.  The memory lives until the process ends (tests and the bench allocate a handful)."""
+    lib = _lib.load()
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    nbytes = max(1, int(np.prod(shape)) * np.dtype(dtype).itemsize)
+    p = lib.rk_host_alloc(nbytes)
+    if not p:
+        raise _lib.RkError(_lib.RK_ERR_NOMEM, lib.rk_last_error().decode("utf-8", "replace"))
+    return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)).view(dtype)[:int(np.prod(shape))].reshape(shape)
+
+
 def validate_db(alphabet, k, n_branches, thr_log10, thr, key_codes, row_offsets, branch_ids, scores,
                 table_mode=RK_TABLE_AUTO, convert_uo=False):
     """rk_db_validate: argument checks + host-side image construction, no device needed. Returns rk_db_info."""

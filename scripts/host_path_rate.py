@@ -33,3 +33,17 @@ def rate(fn, reps=3):
 
 print(f"rk_place_batch_packed, pageable: {rate(lambda: pp.processQueriesPacked(packed, fixed_len=150, out=reuse)):.1f} Mreads/s")
 print(f"rk_place_batch (ASCII), pageable: {rate(lambda: pp.processQueries(seq, off, out=reuse)):.1f} Mreads/s")
+
+# page-locked caller buffers (rk_host_alloc): the DMA reads / writes them directly, no staging copies
+lib.rk_host_alloc.restype = C.c_void_p
+def pinned(shape, dtype):
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib.rk_host_alloc(nbytes)
+    return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)).view(dtype).reshape(shape)
+preuse = ra.Placements(pinned(n, np.uint8), pinned((n, K), np.uint16), pinned((n, K), np.float32), pinned((n, K), np.float64), pinned(n, np.uint32), {})
+ppacked = pinned(packed.shape, np.uint32); ppacked[:] = packed
+print(f"rk_place_batch_packed, page-locked in + out: {rate(lambda: pp.processQueriesPacked(ppacked, fixed_len=150, out=preuse)):.1f} Mreads/s")
+print(f"rk_place_batch_packed, pageable in, page-locked out: {rate(lambda: pp.processQueriesPacked(packed, fixed_len=150, out=preuse)):.1f} Mreads/s")
+for cr in (1 << 18, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 18):
+    os.environ["RK_CHUNK_READS"] = str(cr)
+    print(f"chunk {cr}: packed pageable {rate(lambda: pp.processQueriesPacked(packed, fixed_len=150, out=reuse)):.1f}  page-locked {rate(lambda: pp.processQueriesPacked(ppacked, fixed_len=150, out=preuse)):.1f} Mreads/s")

@@ -43,7 +43,7 @@ if prefix:
     with open(prefix + "_pmc_summary.txt", "w") as fh:
         fh.write("\n".join(lines) + "\n")
     for k, d in agg.items():
-        if "place_packed_kernel" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        if "rk::place_" in k and "place_ascii" not in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
             write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
             meta = json.loads(os.environ.get("PROF_META", "{}"))

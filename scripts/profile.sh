@@ -2,13 +2,13 @@
 # rocprofv3 passes for the placement kernel (run on the GPU box through gpurun).
 # usage: scripts/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --verify 0 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --verify 0 --no-cpu-baseline --no-pcie $*"
 run() { # name, rocprof args...
   local name=$1; shift
   timeout -k 10 280 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
