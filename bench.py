@@ -23,8 +23,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: enough for about 1-10 s of GPU time: 200 for C1/C2/C4, 10 for C3/C5s/C5m, 3 for C5)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default: 10, or 1 for the long configs)")
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "C5mini", "C5s", "C5m"],
                     help="C2 = the configuration BASELINE's metric is quoted on (default); C3 = C2's DB with 1.25e8 reads per GPU "
                          "(1e9 reads over 8 GPUs); C5 = 10k-leaf tree, k=12, ~200 GB DB generated on the device, 1.25e7 x 250 bp per GPU")
@@ -39,7 +39,13 @@ def parse():
     ap.add_argument("--db-scale", type=float, default=1.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse the multi-rank path on one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
-    return ap.parse_args()
+    a = ap.parse_args()
+    long_cfg = {"C3": 10, "C5": 3, "C5s": 10, "C5m": 5, "C5mini": 20}
+    if a.steps <= 0:
+        a.steps = long_cfg.get(a.config, 200)
+    if a.warmup < 0:
+        a.warmup = 1 if a.config in long_cfg else 10
+    return a
 
 
 def unpack_to_ascii(alphabet, packed_np, length):
