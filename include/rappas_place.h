@@ -127,6 +127,10 @@ int rk_db_create(const rk_db_desc *desc, rk_db **out);
  * (or a CPU-only test) validate a DB and learn its HBM footprint / table flavour.  info may be NULL. */
 int rk_db_validate(const rk_db_desc *desc, rk_db_info *info);
 void rk_db_destroy(rk_db *db);
+/* Another handle of the same database on `device` (it may be the source's own device), copied device to device -- over xGMI
+ * between GPUs -- instead of being rebuilt and uploaded once per GPU: what a single-process caller (one JVM, rk_place_batch_multi)
+ * does after the first rk_db_create, and the only way to replicate an image that exists in HBM only (rk_db_create_synth). */
+int rk_db_clone(const rk_db *src, int32_t device, rk_db **out);
 int rk_db_get_info(const rk_db *db, rk_db_info *info);
 
 /* One row read back out of the HBM image through the same table lookup and entry decode the placement kernels use:

@@ -76,6 +76,7 @@ EXPORTS = {
     "rk_db_create": (C.c_int, [C.POINTER(rk_db_desc), C.POINTER(C.c_void_p)]),
     "rk_db_validate": (C.c_int, [C.POINTER(rk_db_desc), C.POINTER(rk_db_info)]),
     "rk_db_destroy": (None, [C.c_void_p]),
+    "rk_db_clone": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "rk_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(rk_db_info)]),
     "rk_db_fetch_row": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rk_db_create_synth": (C.c_int, [C.POINTER(rk_synth_desc), C.POINTER(C.c_void_p)]),

@@ -688,6 +688,53 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     return RK_OK;
 }
 
+// A second handle of the same database on another (or the same) device, copied device to device: the image is not rebuilt and
+// nothing goes back through the host (a C5-class image is 200 GB; xGMI moves it in seconds, the host could not even hold it).
+extern "C" int rk_db_clone(const rk_db *src, int32_t device, rk_db **out) {
+    if (!src || !out) return fail(RK_ERR_INVALID, "rk_db_clone: null argument");
+    *out = nullptr;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+    DbMeta meta{src->info.alphabet, src->convert_uo, src->info.k, src->info.n_branches, src->info.thr_log10, src->info.thr};
+    rk_db *db = nullptr;
+    int rc = open_db(meta, device, &db);
+    if (rc) return rc;
+#define CL_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            int c_ = fail(e_ == hipErrorOutOfMemory ? RK_ERR_NOMEM : RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            rk_db_destroy(db);                                                                    \
+            return c_;                                                                            \
+        }                                                                                         \
+    } while (0)
+    const size_t table_bytes = src->info.table_bytes, blob_bytes = src->info.rows_bytes;
+    const int sdev = src->info.device;
+    auto copy = [&](void *dst, const void *from, size_t bytes) {
+        return device == sdev ? hipMemcpy(dst, from, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, device, from, sdev, bytes);
+    };
+    CL_TRY(hipMalloc(&db->d_table, table_bytes ? table_bytes : 8));
+    CL_TRY(hipMalloc(&db->d_rows, blob_bytes));
+    if (table_bytes) CL_TRY(copy(db->d_table, src->d_table, table_bytes));
+    CL_TRY(copy(db->d_rows, src->d_rows, blob_bytes));
+    if (src->windowed) {
+        uint64_t space = 0;
+        (void)ipow_fits(src->info.alphabet, src->info.k, 1ull << 40, space);
+        CL_TRY(hipMalloc((void **)&db->d_winspec, space));
+        CL_TRY(copy(db->d_winspec, src->d_winspec, space));
+        db->windowed = true;
+        db->wp = src->wp;
+    }
+    CL_TRY(hipDeviceSynchronize());
+#undef CL_TRY
+    finish_db(db, meta, src->info.table_mode, src->indexed, src->view.mono != 0, src->info.n_keys, src->info.n_entries, src->info.table_slots,
+              src->view.hash_mask, table_bytes, blob_bytes, src->info.max_row_len);
+    db->lanes_per_read = src->lanes_per_read;
+    *out = db;
+    return RK_OK;
+}
+
 extern "C" int rk_db_get_info(const rk_db *db, rk_db_info *info) {
     if (!db || !info) return fail(RK_ERR_INVALID, "rk_db_get_info: null argument");
     *info = db->info;

@@ -98,6 +98,17 @@ class PhyloKmerDB:
         self.info = info
         return self
 
+    def clone(self, device=0):
+        """rk_db_clone: another handle of this database on `device`, copied device to device (no rebuild, no host round trip)."""
+        other = type(self).__new__(type(self))
+        other._lib = self._lib
+        other._h = C.c_void_p()
+        _lib.check(self._lib.rk_db_clone(self.handle, device, C.byref(other._h)))
+        info = rk_db_info()
+        _lib.check(self._lib.rk_db_get_info(other._h, C.byref(info)))
+        other.info = info
+        return other
+
     def fetch_row(self, code):
         """(branch_ids u16[len], scores f32[len]) of one k-mer code as stored in the HBM image; empty arrays if absent
         (CustomHash_v4_FastUtil81.getPairsOfTopPosition2, src/core/hash/CustomHash_v4_FastUtil81.java:146-153)."""

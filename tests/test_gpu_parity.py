@@ -650,3 +650,30 @@ def test_windowed_and_dense_kernels_agree(monkeypatch):
         assert np.array_equal(a.score.view(np.uint32), b.score.view(np.uint32))
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("shape", ["small", "windowed", "large_tree"])
+def test_cloned_handles_place_identically(shape):
+    """rk_db_clone: device-to-device copy of the image (table, rows, window spans); shards over the source and two clones give the
+    single-call records"""
+    sdb = {"small": lambda: synth.make_config_db("C1"), "windowed": lambda: synth.make_db(4, 8, 4001, 30000, 400000, seed=2),
+           "large_tree": lambda: synth.make_db(4, 6, 20001, 3000, 600000, seed=3)}[shape]()
+    seq, off = synth.make_reads(4, 3000, 150, seed=9, amb_rate=0.001)
+    a = ra.PhyloKmerDB.from_synth(sdb)
+    b = a.clone(0)
+    c = b.clone(0)
+    try:
+        assert b.kernel_name() == a.kernel_name() and b.info.rows_bytes == a.info.rows_bytes and b.info.n_entries == a.info.n_entries
+        pp = ra.PlacementProcess(a)
+        want = pp.processQueries(seq, off)
+        got = pp.processQueriesMulti([a, b, c], seq, off)
+        alone = ra.PlacementProcess(c).processQueries(seq, off)
+        for g in (got, alone):
+            for f in ("n_rows", "branch", "flags", "lwr"):
+                assert np.array_equal(getattr(g, f), getattr(want, f))
+            assert np.array_equal(g.score.view(np.uint32), want.score.view(np.uint32))
+        code = int(sdb.key_codes[5])
+        assert all(np.array_equal(x, y) for x, y in zip(a.fetch_row(code), c.fetch_row(code)))
+    finally:
+        for d in (a, b, c):
+            d.close()
