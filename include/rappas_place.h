@@ -72,7 +72,7 @@ typedef struct rk_db rk_db;
 typedef struct rk_db_desc {
     uint32_t alphabet;    /* RK_ALPHABET_DNA | RK_ALPHABET_AA */
     uint32_t convert_uo;  /* AA only: U->C, O->L (src/core/AAStates.java:118-123) */
-    uint32_t k;           /* DNA: 2..15, AA: 2..12 */
+    uint32_t k;           /* DNA: 2..31 (hashed table from k = 16: 4^k codes), AA: 2..12 */
     uint32_t n_branches;  /* originalTree.getNodeCount() (PlacementProcess.java:495-496); branch ids < n_branches <= 65535 */
     float thr_log10;      /* session.PPStarThresholdAsLog10 (T) */
     float thr;            /* session.PPStarThreshold (P), used by the ambiguity-mean path */

@@ -436,18 +436,22 @@ static uint32_t score_read(const ro_db *db, work_t *w, int amb_mode, const uint8
         } else if (amb_mode == RO_AMB_SKIP) {
             ct->skipped_kmers++; /* --noamb: PlacementProcess.java:745-749 */
         } else {
-            /* exactly one ambiguous position (max_amb == 1 for every supported k; the >=2 enumeration of
-             * AmbigSequenceKnife.java:235-260 is not a cartesian product and is unreachable for DNA k<16 / AA) */
-            if (max_amb != 1) { ct->skipped_kmers++; continue; }
+            /* 1 .. max_amb ambiguous positions (max_amb = 1 for DNA k < 16 and every protein k, 2 for DNA k = 16 .. 80).
+             * AmbigSequenceKnife.java:235-260: altProduct = product of the alternative counts; word j takes, at EVERY ambiguous
+             * position i, alt_i[j mod len_i] (the `jump` counter runs 0 .. altProduct-1 for each position on its own) -- the
+             * cartesian product only when the counts are coprime; with two positions of equal count the same words come
+             * up several times, and PlacementProcess counts each occurrence (W_size = words.length / k, :1133). */
             ct->amb_kmers++;
-            int p = -1;
-            for (int i = 0; i < k; i++) { window[i] = (uint8_t)w->seq[j + i]; if (w->seq[j + i] == -1) p = i; }
-            uint8_t alts[20];
-            int W = ro_amb_alternatives(db->alphabet, w->cls[j + p], alts);
-            int64_t rows[20];
+            int pos[4], np = 0;
+            for (int i = 0; i < k; i++) { window[i] = (uint8_t)w->seq[j + i]; if (w->seq[j + i] == -1 && np < 4) pos[np++] = i; }
+            uint8_t alts[4][20];
+            int nalt[4], W = 1;
+            for (int q = 0; q < np; q++) { nalt[q] = ro_amb_alternatives(db->alphabet, w->cls[j + pos[q]], alts[q]); W *= nalt[q]; }
+            if (W > 400) { ct->skipped_kmers++; continue; } /* (unreachable: <= 2 positions for every k this oracle accepts) */
+            static __thread int64_t rows[400];
             int any = 0;
-            for (int a = 0; a < W; a++) { /* words[i+j*k]=alt[j] (:251-255) */
-                window[p] = alts[a];
+            for (int a = 0; a < W; a++) { /* words[i+jump*k]=alt_i[jump % len_i] (:249-256) */
+                for (int q = 0; q < np; q++) window[pos[q]] = alts[q][a % nalt[q]];
                 rows[a] = db_get(db, ro_kmer_code(db->alphabet, window, k));
                 if (rows[a] >= 0) any = 1;
             }

@@ -418,7 +418,9 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     if (d->alphabet != RK_ALPHABET_DNA && d->alphabet != RK_ALPHABET_AA)
         return fail(RK_ERR_INVALID, "rk_db_create: alphabet must be 4 (DNA) or 20 (AA), got %u", d->alphabet);
     const uint32_t bits = d->alphabet == RK_ALPHABET_DNA ? 2 : 5;
-    const uint32_t kmax = d->alphabet == RK_ALPHABET_DNA ? 15 : 12;
+    // DNA: 2 bits per base in a 64-bit code; from k = 16 on the reference allows two ambiguity codes per k-mer
+    // (maxAmbigPerMer = floor(k^(1/4)), AmbigSequenceKnife.java:95), three only from k = 81.  AA: 5 bits per residue.
+    const uint32_t kmax = d->alphabet == RK_ALPHABET_DNA ? 31 : 12;
     if (d->k < 2 || d->k > kmax)
         return fail(RK_ERR_UNSUPPORTED, "rk_db_create: k=%u outside supported range 2..%u for this alphabet", d->k, kmax);
     if (d->n_branches < 1 || d->n_branches > 65535)

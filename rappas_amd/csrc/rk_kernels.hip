@@ -114,7 +114,7 @@ __device__ __forceinline__ u64 extract_code(const u32 *rec, u32 words, u32 j, u3
     const u64 lo = ((u64)w1 << 32) | w0;
     u64 code = lo >> sh;
     const u32 nbits = k * BITS;
-    if (BITS * 12 + 31 > 64) {  // AA with k >= 7 can need a third word
+    if (BITS == 5 || nbits + 31 > 64) {  // AA with k >= 7 and DNA with k >= 17 can need a third word (uniform test)
         const u32 i2 = wi + 2 < words ? wi + 2 : last;
         u32 w2 = rec[i2];
         w2 = (wi + 2 < words && nbits + sh > 64) ? w2 : 0u;
@@ -1917,13 +1917,23 @@ struct AmbArgs {
 template <int BITS, int TM>
 __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &m, u32 *S, float *Samb, u32 *Camb,
                                              u32 chunk, u64 code, u32 p, u32 cls, u32 lane, float QT, bool have_pre,
-                                             const u64 (&pre)[4], u32 s_lo, u32 nb) {
+                                             const u64 (&pre)[4], u32 s_lo, u32 nb, u32 p2 = 0, u32 cls2 = 0xFFu) {
     // S, Samb and Camb hold the branches [s_lo, s_lo + nb) of the tree (the whole tree unless it exceeds the LDS: then the read
     // is walked once per window); ids outside the window are dropped right after they are loaded
     const float T = a.db.T, P = a.db.P;
-    const u32 W = m.alt_count[cls];
+    // One ambiguous position: its alternatives in table order.  Two (DNA k >= 16 only, maxAmbigPerMer = 2): word number w takes
+    // alt[w % count] at EACH position, count1 * count2 words in all (AmbigSequenceKnife.java:235-260) -- the cartesian product only
+    // when the counts are coprime; repeated words are looked up and counted again, as the reference does.
+    const bool two = cls2 != 0xFFu;
+    const u32 W1 = m.alt_count[cls], W2 = two ? m.alt_count[cls2] : 1u;
+    const u32 W = W1 * W2;
+    auto word = [&](u32 w) {
+        u64 cw = code | ((u64)m.alt_table[cls * 20 + w % W1] << (BITS * p));
+        if (two) cw |= (u64)m.alt_table[cls2 * 20 + w % W2] << (BITS * p2);
+        return cw;
+    };
     auto rebase = [&](u32 &x) { const u32 xw = x - s_lo; x = (xw < nb) ? xw : 0xFFFFu; };  // (padding 0xFFFF stays 0xFFFF)
-    if (W <= 4 && chunk >= nb) {
+    if (!two && W <= 4 && chunk >= nb) {
         // fast path (DNA: <= 4 alternatives; one Samb/Camb window covers the tree): the alternatives' descriptors are
         // looked up together and, when every row fits the wave, their entries are loaded once into registers; the
         // per-branch updates still run alternative by alternative, in the reference's order
@@ -2054,7 +2064,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
     for (u32 lo = 0; lo < nb; lo += chunk) {
         // pass 1: gather alternatives into Samb / Camb (sequential over alternatives)
         for (u32 w = 0; w < W; w++) {
-            u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
+            const u64 cw = word(w);
             u64 desc = lookup_desc<BITS, TM>(a.db, cw);
             u32 len = (u32)desc & DESC_LEN_MASK;
             if (!len) continue;
@@ -2080,7 +2090,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
         // pass 2: fold into S; the first alternative row that lists x does it (per-branch updates are independent,
         // so the L_amb visiting order does not change any S[x])
         for (u32 w = 0; w < W; w++) {
-            u64 cw = code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p));
+            const u64 cw = word(w);
             u64 desc = lookup_desc<BITS, TM>(a.db, cw);
             u32 len = (u32)desc & DESC_LEN_MASK;
             if (!len) continue;
@@ -2246,16 +2256,19 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         const u32 clo = (u32)__builtin_amdgcn_readlane((int)(u32)code, (int)na);
                         const u32 chi = (u32)__builtin_amdgcn_readlane((int)(u32)(code >> 32), (int)na);
                         const u64 codeA = ((u64)chi << 32) | clo;
-                        if (__builtin_popcount(maskA) == 1 && m.max_amb >= 1 && m.amb_mode != RK_AMB_SKIP) {
+                        const u32 n_amb = (u32)__builtin_popcount(maskA);
+                        if (n_amb >= 1 && n_amb <= m.max_amb && n_amb <= 2 && m.amb_mode != RK_AMB_SKIP) {
                             const u32 p = __builtin_ctz(maskA);
                             const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
-                            const bool have_pre = __builtin_amdgcn_readlane((int)pre_ok, (int)na) != 0;
+                            const u32 p2 = 31u - (u32)__builtin_clz(maskA);  // the second ambiguous position (DNA k >= 16), == p otherwise
+                            const u32 cls2 = n_amb == 2 ? (u32)(m.char_table[s[j0 + na + p2]] & 0x7F) : 0xFFu;
+                            const bool have_pre = n_amb == 1 && __builtin_amdgcn_readlane((int)pre_ok, (int)na) != 0;
                             u64 pre[4];
 #pragma unroll
                             for (int w = 0; w < 4; w++)
                                 pre[w] = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(alt_d[w] >> 32), (int)na) << 32) |
                                          (u32)__builtin_amdgcn_readlane((int)(u32)alt_d[w], (int)na);
-                            if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT, have_pre, pre, s_lo, nb);
+                            if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT, have_pre, pre, s_lo, nb, p2, cls2);
                         }
                         amb_b &= amb_b - 1;
                         p0 = na + 1;

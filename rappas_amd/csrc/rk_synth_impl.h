@@ -122,7 +122,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     *out = nullptr;
     if (d->alphabet != RK_ALPHABET_DNA && d->alphabet != RK_ALPHABET_AA)
         return fail(RK_ERR_INVALID, "rk_db_create_synth: alphabet must be 4 (DNA) or 20 (AA), got %u", d->alphabet);
-    const uint32_t kmax = d->alphabet == RK_ALPHABET_DNA ? 15 : 12;
+    const uint32_t kmax = d->alphabet == RK_ALPHABET_DNA ? 31 : 12;
     if (d->k < 2 || d->k > kmax) return fail(RK_ERR_UNSUPPORTED, "rk_db_create_synth: k=%u outside supported range 2..%u", d->k, kmax);
     if (d->n_branches < 1 || d->n_branches > 65535) return fail(RK_ERR_INVALID, "rk_db_create_synth: n_branches=%u must be in 1..65535", d->n_branches);
     if (!std::isfinite(d->thr_log10) || !std::isfinite(d->thr)) return fail(RK_ERR_INVALID, "rk_db_create_synth: thresholds must be finite");

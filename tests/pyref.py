@@ -160,15 +160,21 @@ def place_read(db, read, keep_at_most=7, keep_factor=0.01, amb_mode="mean", ns_b
                 touch(x)
                 S[x] = f32(S[x] + f32(f32(v) - T))
                 H += 1
-        elif amb[j] > max_amb or amb_mode == "skip" or max_amb != 1:
+        elif amb[j] > max_amb or amb_mode == "skip":
             continue
         else:
-            p = next(i for i in range(k) if seq[j + i] == -1)
-            W = len(alts[j + p])
+            # AmbigSequenceKnife.java:235-260: word number `jump` takes alt_i[jump % len_i] at EVERY ambiguous position i
+            # (the counter restarts for each position), altProduct words in all -- not a cartesian product unless the counts
+            # are coprime; one ambiguous position (all that DNA k < 16 and proteins allow) gives its alternatives in order
+            ps = [i for i in range(k) if seq[j + i] == -1]
+            W = 1
+            for p in ps:
+                W *= len(alts[j + p])
             S_amb, C_amb, L_amb = {}, {}, []
-            for a in alts[j + p]:
+            for jump in range(W):
                 w = list(seq[j:j + k])
-                w[p] = a
+                for p in ps:
+                    w[p] = alts[j + p][jump % len(alts[j + p])]
                 row = db["rows"].get(kmer_code(alphabet, w))
                 if row is None:
                     continue

@@ -67,7 +67,7 @@ def test_argument_validation_without_device():
     d = _lib.rk_db_desc(alphabet=7, k=8, n_branches=10)
     assert lib.rk_db_create(C.byref(d), C.byref(h)) == _lib.RK_ERR_INVALID
     assert b"alphabet" in lib.rk_last_error()
-    d = _lib.rk_db_desc(alphabet=4, k=16, n_branches=10)
+    d = _lib.rk_db_desc(alphabet=4, k=32, n_branches=10)  # 2 bits per base in a 64-bit code: k <= 31
     assert lib.rk_db_create(C.byref(d), C.byref(h)) == _lib.RK_ERR_UNSUPPORTED
     d = _lib.rk_db_desc(alphabet=4, k=8, n_branches=70000)
     assert lib.rk_db_create(C.byref(d), C.byref(h)) == _lib.RK_ERR_INVALID

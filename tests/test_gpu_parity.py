@@ -677,3 +677,29 @@ def test_cloned_handles_place_identically(shape):
     finally:
         for d in (a, b, c):
             d.close()
+
+
+# ---- DNA k >= 16: hashed table (4^k codes), up to two ambiguity codes per k-mer (AmbigSequenceKnife.java:95,235-260) ----
+@pytest.mark.parametrize("k", [16, 17, 24, 31])
+@pytest.mark.parametrize("amb", ["mean", "max", "skip"])
+def test_long_kmers_and_two_ambiguity_codes_per_kmer(k, amb):
+    sdb, genome = synth.make_motif_db(k, 700, genome_len=3000, seed=k)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_motif_reads(genome, 1500, 150, seed=4, amb_rate=0.012, var_len=60)
+    got, ref, st = run_case(sdb, odb, seq, off, "hash", 0, amb)
+    assert st["placed"] > 1400
+    lens = (off[1:] - off[:-1]).astype(int)
+    n_amb = np.add.reduceat((~np.isin(seq, np.frombuffer(b"ATCG", np.uint8))).astype(int), off[:-1].astype(int))
+    assert (n_amb >= 2).sum() > 200  # plenty of reads with two and more ambiguity codes
+
+
+def test_long_kmers_large_tree_and_lane_widths():
+    sdb, genome = synth.make_motif_db(18, 20001, genome_len=2000, mean_row=150, seed=3)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_motif_reads(genome, 300, 200, seed=5, amb_rate=0.008)
+    run_case(sdb, odb, seq, off, "hash", 0, "mean")
+    sdb2, genome2 = synth.make_motif_db(20, 300, genome_len=2000, seed=8)
+    odb2 = O.OracleDB.from_synth(sdb2)
+    seq2, off2 = synth.make_motif_reads(genome2, 500, 150, seed=6, amb_rate=0.01)
+    for lanes in (8, 16, 32, 64):
+        run_case(sdb2, odb2, seq2, off2, "hash", lanes, "mean")

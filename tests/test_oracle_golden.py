@@ -160,3 +160,66 @@ def test_oracle_tie_flag_and_counters():
     assert r["flags"][1] == 0 and r["n_rows"][1] == 0
     c = r["counters"]
     assert (c["reads"], c["placed"], c["unplaced"], c["kmers"]) == (2, 1, 1, 7 + 5)
+
+
+# ---- DNA k >= 16: two ambiguity codes per k-mer are allowed (maxAmbigPerMer = floor(k^(1/4)) = 2, AmbigSequenceKnife.java:95) ----
+def test_two_ambiguities_follow_the_reference_enumeration_not_the_cartesian_product():
+    """AmbigSequenceKnife.java:235-260: with alternatives R = {A, G} and Y = {C, T} in one 16-mer the four words are
+    (A,C) (G,T) (A,C) (G,T): word `jump` takes alt[jump % len] at each position.  (A,T) and (G,C) are never looked up, and the
+    two words that are looked up count twice.  Expected score written out in float32 by hand (PlacementProcess.java:1129-1174)."""
+    f32 = np.float32
+    k, nb = 16, 5
+    P, T = synth.thresholds(1.5, 4, k)
+    base = "ACGTTGCAAGGCTTAC"
+    read = base[:3] + "R" + base[4:9] + "Y" + base[10:]          # R at window position 3, Y at position 9
+    code = lambda w: sum("ATCG".index(c) << (2 * i) for i, c in enumerate(w))
+    word = lambda a, b: base[:3] + a + base[4:9] + b + base[10:]
+    v_ac, v_gt, v_at = f32(-1.5), f32(-0.25), f32(-0.0625)
+    codes = np.array([code(word("A", "C")), code(word("G", "T")), code(word("A", "T"))], np.uint64)
+    odb = O.OracleDB(4, k, nb, T, P, codes, np.array([0, 1, 2, 3], np.uint64), np.array([1, 1, 2], np.uint16), np.array([v_ac, v_gt, v_at], np.float32))
+    seq = np.frombuffer(read.encode(), np.uint8)
+    r = odb.place(seq, np.array([0, 16], np.uint64), keep_at_most=3)
+    # mean: S_amb is a float that receives double additions, in word order (A,C) (G,T) (A,C) (G,T); C_amb = 4 = W
+    s_amb = f32(0.0)
+    for v in (v_ac, v_gt, v_ac, v_gt):
+        s_amb = f32(float(s_amb) + 10.0 ** float(v))
+    avg = f32(f32(s_amb + f32(f32(4 - 4) * P)) / f32(4))
+    import math
+    want = f32(float(f32(f32(1) * T)) + (math.log10(float(avg)) - float(T)))   # Q = 1
+    assert int(r["n_rows"][0]) == 1 and int(r["branch"][0, 0]) == 1             # branch 2 ((A,T) only) is never touched
+    assert r["score"][0, 0].view(np.uint32) == want.view(np.uint32)
+    assert int(r["entries"][0]) == 4
+    # max: the larger of the two scores
+    r = odb.place(seq, np.array([0, 16], np.uint64), keep_at_most=3, amb_mode=O.AMB_MAX)
+    assert r["score"][0, 0].view(np.uint32) == f32(f32(f32(1) * T) + f32(v_gt - T)).view(np.uint32)
+    # coprime counts do give the cartesian product: R = {A, G} x B = {C, G, T} -> 6 distinct words
+    read2 = base[:3] + "R" + base[4:9] + "B" + base[10:]
+    r = odb.place(np.frombuffer(read2.encode(), np.uint8), np.array([0, 16], np.uint64), keep_at_most=3)
+    assert sorted(r["branch"][0, :2].tolist()) == [1, 2] and int(r["entries"][0]) == 3
+
+
+@pytest.mark.parametrize("k", [16, 17, 20])
+@pytest.mark.parametrize("amb", ["mean", "max", "skip"])
+def test_oracle_matches_python_restatement_two_ambiguities(k, amb):
+    sdb, genome = synth.make_motif_db(k, 60, genome_len=300, seed=k)
+    rows = {}
+    for r in range(sdb.n_keys):
+        a, b = int(sdb.row_offsets[r]), int(sdb.row_offsets[r + 1])
+        rows[int(sdb.key_codes[r])] = [(int(x), np.float32(v)) for x, v in zip(sdb.branch_ids[a:b], sdb.scores[a:b])]
+    db = dict(alphabet=4, k=k, n_branches=60, T=sdb.thr_log10, P=sdb.thr, rows=rows)
+    seq, off = synth.make_motif_reads(genome, 50, 60, seed=2, amb_rate=0.06, var_len=30)
+    odb = O.OracleDB.from_synth(sdb)
+    r = odb.place(seq, off, keep_at_most=5, keep_factor=0.05, amb_mode=GU.AMB[amb])
+    two = 0
+    for i in range(len(off) - 1):
+        rd = bytes(seq[int(off[i]):int(off[i + 1])]).decode()
+        e = pyref.place_read(db, rd, keep_at_most=5, keep_factor=0.05, amb_mode=amb)
+        assert int(r["flags"][i]) & ~O.RO_FLAG_TIE == sum(GU.FLAG_BITS[f] for f in e["flags"]), (i, rd)
+        assert int(r["n_rows"][i]) == len(e["rows"]), (i, rd)
+        for j, (b, sc, w) in enumerate(e["rows"]):
+            assert int(r["branch"][i, j]) == b and r["score"][i, j].view(np.uint32) == np.float32(sc).view(np.uint32), (i, j, rd)
+            assert abs(r["lwr"][i, j] - w) <= 1e-14 * abs(w)
+        assert int(r["entries"][i]) == e["H"]
+        amb_pos = [p for p, c in enumerate(rd) if c not in "ATCG"]
+        two += any(0 < q - p < k for p, q in zip(amb_pos, amb_pos[1:]))
+    assert two > 5  # reads with two ambiguity codes inside one window were part of it
