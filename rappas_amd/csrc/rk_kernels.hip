@@ -22,7 +22,7 @@
 #define RK_ROW_NT 0
 #endif
 #ifndef RK_ABLATE
-#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate (outputs are then wrong)
+#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate, 512 / 1024 / 2048 = windowed kernel without accumulate / with the exact select only in the last window / without compaction and accumulate (outputs are then wrong)
 #endif
 #include "../../include/rappas_place.h"
 
