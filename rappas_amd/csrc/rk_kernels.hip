@@ -1215,6 +1215,10 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
         }
     };
 
+#ifdef RK_STAMPS
+    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_ = rk_now();
+#endif
     // prologue: the first tile's inputs and its first batch of descriptors
     u32 c_recw, c_R, c_fin;
     bool c_have;
@@ -1337,6 +1341,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
             }
         };
 
+        RK_STAMP(0);  // tile setup
         emit_batch(desc0, Q > 0);
         for (u32 pos = PU * G; __any(pos < Q); pos += PU * G) {  // reads longer than PU*16 + k - 1 symbols
             u64 code[PU], desc[PU];
@@ -1346,24 +1351,34 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
             decode_batch(code, raw, pos, Q, desc);
             emit_batch(desc, pos < Q);
         }
+        RK_STAMP(2);  // scans + item emission
         // next tile's inputs: in flight during this tile's accumulate phase
         load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
         if (__any(cnt > 0)) flush();
+        RK_STAMP(4);  // accumulate (incl. its fences)
         // next tile's first batch of table gathers: in flight during this tile's select phase
         u64 ncode[PU];
         RawSlot nraw[PU];
         const u32 nQ = mer_count(c_R, c_fin, c_have);
         fetch_batch(c_recw, 0u, nQ, ncode, nraw);
         __builtin_amdgcn_sched_barrier(0);
+        RK_STAMP(1);  // next tile's codes + gather issue
 
         u64 win_key;
-        const int numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key);
+        const int numBest = select_topk<G>(S, nb, li, gi, (int)a.keep_at_most, list, (int)a.list_cap, win_key RK_STAMP_ARGS);
         wave_lds_fence();
+        RK_STAMP(5);  // select (rest: reset)
         decode_batch(ncode, nraw, 0u, nQ, desc0);  // (before this tile's stores, so that the wait covers loads only)
         __builtin_amdgcn_sched_barrier(0);
+        RK_STAMP(3);  // decode of the next tile's descriptors (waits for its gathers)
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, win_key, flags);
+        RK_STAMP(6);  // weigh + store
     }
+#ifdef RK_STAMPS
+    if (lane == 0 && wave_global < 4096)
+        for (int i = 0; i < 16; i++) rk_stamp_buf[wave_global * 16 + i] = st_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1592,6 +1607,9 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         // the tile is redone with the exact select of every window and a merge of the windows' K best.
         u64 acc_key = 0;  // lane r < K: rank-r key (low 16 bits: 0xFFFF - tree branch id)
         bool doubt = false;
+#ifdef RK_STAMPS
+        unsigned long long st_[16] = {0}, t_ = 0;  // (no phase stamps in this kernel; select_topk wants the pair)
+#endif
         {
             Top3 t3;
             top3_clear(t3);
@@ -1611,7 +1629,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 const u32 win_n = nb - wlo < W ? nb - wlo : W;
             // ---- select over the window, merged into the K best so far ----
             u64 win_key = 0;
-            if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key);  // (timing only)
+            if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key RK_STAMP_ARGS);  // (timing only)
             wave_lds_fence();
             if (win_key != 0ull) win_key -= (u64)wlo;  // window-relative branch -> tree id (low 16 bits hold 0xFFFF - branch)
             const u64 moved = ((u64)row_ror32<8>((u32)(win_key >> 32)) << 32) | row_ror32<8>((u32)win_key);  // lane r -> lane r + 8

@@ -2,12 +2,14 @@
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = "/tmp/librk_stamps.so"
+so = os.path.join(ROOT, "rappas_amd", "variants", "librk_stamps.so")
 extra = sys.argv[1:]
 flags = [a for a in extra if a.startswith("-D")]
 table = next((a.split("=")[1] for a in extra if a.startswith("--table=")), "auto")
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DRK_STAMPS"] + flags +
-               ["-o", so, os.path.join(ROOT, "rappas_amd/csrc/rk_engine.hip")], check=True)
+if flags or not os.path.exists(so):  # (prebuild it on the build host into rappas_amd/variants/ to save GPU-box time)
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DRK_STAMPS"] + flags +
+                   ["-o", so, os.path.join(ROOT, "rappas_amd/csrc/rk_engine.hip")], check=True)
 os.environ["RK_LIB"] = so
 import numpy as np, torch
 import rappas_amd as ra
