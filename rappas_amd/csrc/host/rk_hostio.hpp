@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -40,15 +41,10 @@ inline std::array<uint8_t, 16> md5(const std::string &msg) {
                               14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
                               4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
     uint32_t h0 = 0x67452301, h1 = 0xefcdab89, h2 = 0x98badcfe, h3 = 0x10325476;
-    std::string m = msg;
-    const uint64_t bitlen = (uint64_t)msg.size() * 8;
-    m.push_back((char)0x80);
-    while (m.size() % 64 != 56) m.push_back('\0');
-    for (int i = 0; i < 8; i++) m.push_back((char)((bitlen >> (8 * i)) & 0xFF));
-    for (size_t off = 0; off < m.size(); off += 64) {
+    auto block = [&](const unsigned char *blk) {
         uint32_t w[16];
         for (int i = 0; i < 16; i++) {
-            const unsigned char *p = (const unsigned char *)m.data() + off + 4 * i;
+            const unsigned char *p = blk + 4 * i;
             w[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
         }
         uint32_t a = h0, b = h1, c = h2, d = h3;
@@ -67,7 +63,21 @@ inline std::array<uint8_t, 16> md5(const std::string &msg) {
             a = tmp;
         }
         h0 += a; h1 += b; h2 += c; h3 += d;
-    }
+    };
+    // whole 64-byte blocks straight from the message, then the padded tail (0x80, zeros, 64-bit bit length) from a small buffer
+    const unsigned char *data = (const unsigned char *)msg.data();
+    const size_t n = msg.size();
+    size_t off = 0;
+    for (; off + 64 <= n; off += 64) block(data + off);
+    unsigned char tail[128] = {0};
+    const size_t rem = n - off;
+    memcpy(tail, data + off, rem);
+    tail[rem] = 0x80;
+    const size_t tail_len = rem < 56 ? 64 : 128;
+    const uint64_t bitlen = (uint64_t)n * 8;
+    for (int i = 0; i < 8; i++) tail[tail_len - 8 + i] = (unsigned char)((bitlen >> (8 * i)) & 0xFF);
+    block(tail);
+    if (tail_len == 128) block(tail + 64);
     std::array<uint8_t, 16> out;
     const uint32_t hs[4] = {h0, h1, h2, h3};
     for (int i = 0; i < 4; i++)
@@ -115,40 +125,80 @@ inline std::vector<Fasta> read_fasta(const std::string &text) {
     return out;
 }
 
-// PlacementProcess.java:591-629: first occurrence keeps its FULL header, later duplicates the header cut at the first space
-inline void dedup_reads(const std::vector<Fasta> &recs, std::vector<Fasta> &unique, std::vector<std::vector<std::string>> &names) {
-    std::map<std::array<uint8_t, 16>, size_t> index;
-    for (const Fasta &f : recs) {
-        std::string nogap;
-        for (char c : f.seq)
-            if (c != '-') nogap.push_back(c);
-        const auto key = md5(nogap);
-        auto it = index.find(key);
-        if (it != index.end()) {
-            const size_t cut = f.header.find(' ');
-            names[it->second].push_back(cut == std::string::npos ? f.header : f.header.substr(0, cut));
-        } else {
-            index[key] = unique.size();
-            unique.push_back(f);
-            names.push_back({f.header});
-        }
+// PlacementProcess.java:591-629: first occurrence keeps its FULL header, later duplicates the header cut at the first space.
+// The checksums (MD5 of the sequence without '-') are independent of each other: they are computed on a few host threads,
+// then the reads are walked in file order through a hash map keyed by the digest (its first 8 bytes are hash enough).
+inline std::array<uint8_t, 16> read_checksum(const Fasta &f) {
+    if (f.seq.find('-') == std::string::npos) return md5(f.seq);
+    std::string nogap;
+    nogap.reserve(f.seq.size());
+    for (char c : f.seq)
+        if (c != '-') nogap.push_back(c);
+    return md5(nogap);
+}
+
+struct DigestHash {
+    size_t operator()(const std::array<uint8_t, 16> &d) const {
+        uint64_t v;
+        memcpy(&v, d.data(), 8);
+        return (size_t)v;
     }
+};
+
+// index form of the dedup: which unique read every record belongs to, and the record that introduced each unique read
+struct Dedup {
+    std::vector<uint32_t> uniq_of_rec;   // [n records]
+    std::vector<uint32_t> first_rec;     // [n unique]
+};
+
+inline Dedup dedup_index(const std::vector<Fasta> &recs, unsigned n_threads = 0) {
+    const size_t n = recs.size();
+    std::vector<std::array<uint8_t, 16>> digest(n);
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = n_threads ? n_threads : std::max(1u, std::min(hw ? hw : 1u, 16u));
+    if (n < 4096) T = 1;
+    auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) digest[i] = read_checksum(recs[i]); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work, n * t / T, n * (t + 1) / T);
+    work(0, n / T);
+    for (std::thread &x : th) x.join();
+    Dedup d;
+    d.uniq_of_rec.resize(n);
+    std::unordered_map<std::array<uint8_t, 16>, uint32_t, DigestHash> index;
+    index.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        auto ins = index.emplace(digest[i], (uint32_t)d.first_rec.size());
+        if (ins.second) d.first_rec.push_back((uint32_t)i);
+        d.uniq_of_rec[i] = ins.first->second;
+    }
+    return d;
+}
+
+// the "nm" lists of the jplace records: the first occurrence's full header, then the space-cut headers of its duplicates
+inline std::vector<std::vector<std::string>> dedup_names(const std::vector<Fasta> &recs, const Dedup &d) {
+    std::vector<std::vector<std::string>> names(d.first_rec.size());
+    for (size_t i = 0; i < recs.size(); i++) {
+        const uint32_t u = d.uniq_of_rec[i];
+        if (d.first_rec[u] == i) { names[u].insert(names[u].begin(), recs[i].header); continue; }
+        const size_t cut = recs[i].header.find(' ');
+        names[u].push_back(cut == std::string::npos ? recs[i].header : recs[i].header.substr(0, cut));
+    }
+    return names;
+}
+
+inline void dedup_reads(const std::vector<Fasta> &recs, std::vector<Fasta> &unique, std::vector<std::vector<std::string>> &names,
+                        unsigned n_threads = 0) {
+    const Dedup d = dedup_index(recs, n_threads);
+    for (uint32_t r : d.first_rec) unique.push_back(recs[r]);
+    names = dedup_names(recs, d);
 }
 
 // notplaced_<query>.tsv (Main_PLACEMENT_v07.java:214, PlacementProcess.java:797-806): the full header of every read that hits
 // nothing in the database, every occurrence (the reference registers checksums of placed reads only, :1046), in file order
-inline std::string notplaced_log(const std::vector<Fasta> &recs, const std::vector<Fasta> &unique, const uint32_t *flags) {
-    std::map<std::array<uint8_t, 16>, size_t> index;
-    auto key_of = [](const std::string &seq) {
-        std::string nogap;
-        for (char c : seq)
-            if (c != '-') nogap.push_back(c);
-        return md5(nogap);
-    };
-    for (size_t i = 0; i < unique.size(); i++) index[key_of(unique[i].seq)] = i;
+inline std::string notplaced_log(const std::vector<Fasta> &recs, const Dedup &d, const uint32_t *flags) {
     std::string out;
-    for (const Fasta &f : recs)
-        if (!(flags[index.at(key_of(f.seq))] & 1u)) { out += f.header; out += "\n"; }
+    for (size_t i = 0; i < recs.size(); i++)
+        if (!(flags[d.uniq_of_rec[i]] & 1u)) { out += recs[i].header; out += "\n"; }
     return out;
 }
 

@@ -2,6 +2,7 @@
 // The reference's `-p p` phase for one query file (src/main_v2/Main_PLACEMENT_v07.java:150-320): ingest and the jplace writer
 // are rk_hostio.hpp, the placement itself is rk_place_batch (GPU; there is no CPU fallback).
 // Same options and byte-identical output as `python -m rappas_amd.tools.place`.
+#include <chrono>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
@@ -71,6 +72,18 @@ int main(int argc, char **argv) {
                     std::cout << "\n";
                 }
                 return 0;
+            } else if (a == "--ingest-rate") {  // N3 throughput: FASTA parse, MD5 dedup, host-side packing (no device needed)
+                const std::string text = slurp(val());
+                auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+                const double t0 = now();
+                const std::vector<rkh::Fasta> recs = rkh::read_fasta(text);
+                const double t1 = now();
+                const rkh::Dedup dd = rkh::dedup_index(recs);
+                const double t2 = now();
+                std::cout << recs.size() << " reads, " << dd.first_rec.size() << " unique, " << text.size() << " bytes\n"
+                          << "parse " << recs.size() / (t1 - t0) / 1e6 << " Mreads/s (" << text.size() / (t1 - t0) / 1e6 << " MB/s)\n"
+                          << "dedup " << recs.size() / (t2 - t1) / 1e6 << " Mreads/s\n";
+                return 0;
             } else if (a == "--load-jsondb") {
                 const rkh::JsonDb db = rkh::load_jsondb(slurp(val()));
                 std::cout << db.k << " " << rkh::java_float_to_string(db.thr) << " " << rkh::java_float_to_string(db.thr_log10) << " "
@@ -100,14 +113,15 @@ int main(int argc, char **argv) {
         rk_db *db = nullptr;
         if (rk_db_create(&d, &db) != RK_OK) throw std::runtime_error(std::string("rk_db_create: ") + rk_last_error());
 
-        std::vector<rkh::Fasta> uniq;
-        std::vector<std::vector<std::string>> names;
         const std::vector<rkh::Fasta> records = rkh::read_fasta(slurp(fasta));
-        rkh::dedup_reads(records, uniq, names);
-        const size_t n = uniq.size();
+        const rkh::Dedup dd = rkh::dedup_index(records);
+        const std::vector<std::vector<std::string>> names = rkh::dedup_names(records, dd);
+        const size_t n = dd.first_rec.size();
         std::string seq;
         std::vector<uint64_t> off(n + 1, 0);
-        for (size_t i = 0; i < n; i++) { seq += uniq[i].seq; off[i + 1] = seq.size(); }
+        for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + records[dd.first_rec[i]].seq.size();
+        seq.reserve(off[n]);
+        for (size_t i = 0; i < n; i++) seq += records[dd.first_rec[i]].seq;
         const uint32_t K = keep_at_most;
         std::vector<uint8_t> n_rows(n);
         std::vector<uint16_t> branch(n * K);
@@ -131,7 +145,7 @@ int main(int argc, char **argv) {
             fs::create_directories(dir);
             std::ofstream nf(dir / ("notplaced_" + fs::path(fasta).filename().string() + ".tsv"), std::ios::binary);
             if (!nf) throw std::runtime_error("cannot write the notplaced log under " + dir.string());
-            nf << rkh::notplaced_log(records, uniq, flags.data());
+            nf << rkh::notplaced_log(records, dd, flags.data());
         }
         std::cerr << n << " unique reads, " << pl.size() << " placed -> " << out << "\n";
         return 0;

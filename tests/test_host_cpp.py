@@ -58,7 +58,7 @@ def test_number_layouts(rk_place):
 
 
 def test_md5_and_dedup(rk_place, tmp_path):
-    for s in ["", "a", "ACGT" * 100, "x" * 55, "y" * 56, "z" * 64]:
+    for s in ["", "a", "ACGT" * 100, "x" * 55, "y" * 56, "w" * 57, "v" * 63, "z" * 64, "u" * 65, "t" * 119, "s" * 120, "r" * 128, "q" * 150]:
         assert run(rk_place, "--md5", s).strip() == hashlib.md5(s.encode()).hexdigest()
     txt = "# c\n>r1 desc\nACGT\n\nAC-GT\n>r2\n  ACGTN  \n>r3 x y\nACGTACGT\n>empty\n>r4\nacgt\n>r5 dup of r1\nACGTACG-T\r\n"
     f = tmp_path / "q.fa"
