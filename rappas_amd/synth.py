@@ -257,21 +257,22 @@ def codes_of_reads(alphabet, k, seq, off):
     return np.concatenate(out) if out else np.zeros(0, dtype=np.uint64)
 
 
-def make_motif_db(k, n_branches, genome_len=400, n_variants=3, mean_row=6, seed=5, omega=1.5):
-    """DNA database for k-mer spaces far too large to sample uniformly (k >= 16: 4^16 codes): the keys are the k-mers of a
-    random "genome" plus, for each, a few one- and two-base variants (so that the alternatives of ambiguity codes hit too).
-    Returns (SynthDB, genome str); reads for it are substrings of the genome (make_motif_reads)."""
+def make_motif_db(k, n_branches, genome_len=400, n_variants=3, mean_row=6, seed=5, omega=1.5, alphabet=4):
+    """Database for k-mer spaces far too large to sample uniformly (DNA k >= 16, amino acids k >= 6): the keys are the k-mers
+    of a random "genome" plus, for each, a few one- and two-symbol variants (so that the alternatives of ambiguity codes hit
+    too).  Returns (SynthDB, genome str); reads for it are substrings of the genome (make_motif_reads)."""
     rng = np.random.default_rng(seed)
-    g = rng.integers(0, 4, size=genome_len)
+    g = rng.integers(0, alphabet, size=genome_len)
+    bits = 2 if alphabet == 4 else 5
     codes = set()
     for j in range(genome_len - k + 1):
         w = g[j:j + k].copy()
-        codes.add(int(sum(int(b) << (2 * i) for i, b in enumerate(w))))
+        codes.add(int(sum(int(b) << (bits * i) for i, b in enumerate(w))))
         for _ in range(n_variants):
             v = w.copy()
             for p in rng.choice(k, size=int(rng.integers(1, 3)), replace=False):
-                v[p] = rng.integers(0, 4)
-            codes.add(int(sum(int(b) << (2 * i) for i, b in enumerate(v))))
+                v[p] = rng.integers(0, alphabet)
+            codes.add(int(sum(int(b) << (bits * i) for i, b in enumerate(v))))
     key_codes = np.array(sorted(codes), dtype=np.uint64)
     rng.shuffle(key_codes)
     n_keys = len(key_codes)
@@ -283,16 +284,23 @@ def make_motif_db(k, n_branches, genome_len=400, n_variants=3, mean_row=6, seed=
     total = int(off[-1])
     within = np.arange(total, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
     branch = (np.repeat(b0, lens) + within).astype(np.uint16)
-    thr, thr_log10 = thresholds(omega, 4, k)
+    thr, thr_log10 = thresholds(omega, alphabet, k)
     scores = (thr_log10 * rng.random(total, dtype=np.float32)).astype(np.float32)
-    return SynthDB(4, k, n_branches, thr, thr_log10, key_codes, off, branch, scores, seed), "".join("ATCG"[b] for b in g)
+    letters = (DNA_LETTERS if alphabet == 4 else AA_LETTERS).tobytes().decode()
+    return SynthDB(alphabet, k, n_branches, thr, thr_log10, key_codes, off, branch, scores, seed), "".join(letters[b] for b in g)
 
 
 def make_motif_reads(genome, n_reads, length, seed=1, amb_rate=0.0, var_len=0):
     """substrings of `genome`; with amb_rate, bases are replaced by an ambiguity code that CONTAINS the base (so the original
     k-mer is among the alternatives).  -> (seq uint8, off uint64)"""
     rng = np.random.default_rng(seed)
-    containing = {"A": "RWMDHVN", "T": "YWKBDHN", "C": "YSMBHVN", "G": "RSKBDVN"}
+    if set(genome) <= set("ATCG"):
+        containing = {"A": "RWMDHVN", "T": "YWKBDHN", "C": "YSMBHVN", "G": "RSKBDVN"}
+    else:  # amino acids: X / * / - stand for all twenty, B = D|N, Z = E|Q, J = I|L
+        containing = {c: "X*-x" for c in AA_LETTERS.tobytes().decode()}
+        for amb, members in (("B", "DN"), ("Z", "EQ"), ("J", "IL")):
+            for c in members:
+                containing[c] += amb * 4
     reads = []
     for _ in range(n_reads):
         L = length - int(rng.integers(0, var_len + 1)) if var_len else length
@@ -300,7 +308,7 @@ def make_motif_reads(genome, n_reads, length, seed=1, amb_rate=0.0, var_len=0):
         r = list(genome[a:a + L])
         if amb_rate > 0:
             for i in np.nonzero(rng.random(len(r)) < amb_rate)[0]:
-                r[i] = containing[r[i]][int(rng.integers(0, 7))]
+                r[i] = containing[r[i]][int(rng.integers(0, len(containing[r[i]])))]
         reads.append("".join(r))
     off = np.zeros(n_reads + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(r) for r in reads])

@@ -693,6 +693,48 @@ def test_long_kmers_and_two_ambiguity_codes_per_kmer(k, amb):
     assert (n_amb >= 2).sum() > 200  # plenty of reads with two and more ambiguity codes
 
 
+# ---- amino acids k = 5..12 (5 bits a symbol: up to 60-bit codes, hashed table), with the B/Z/J/X ambiguity classes ----
+@pytest.mark.parametrize("k", [5, 6, 8, 11, 12])
+@pytest.mark.parametrize("amb", ["mean", "max", "skip"])
+def test_long_protein_kmers(k, amb):
+    sdb, genome = synth.make_motif_db(k, 900, genome_len=2500, seed=40 + k, alphabet=20)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_motif_reads(genome, 1200, 120, seed=9, amb_rate=0.01, var_len=50)
+    got, ref, st = run_case(sdb, odb, seq, off, "hash", 0, amb)
+    assert st["placed"] > 1000
+    if k == 8:
+        for lanes in (16, 32, 64):
+            run_case(sdb, odb, seq, off, "hash", lanes, amb)
+
+
+def test_long_protein_kmers_mid_size_and_large_trees():
+    for nb, seed in ((3999, 1), (7001, 2), (20001, 3), (65535, 4)):
+        sdb, genome = synth.make_motif_db(9, nb, genome_len=1500, mean_row=120, seed=seed, alphabet=20)
+        odb = O.OracleDB.from_synth(sdb)
+        seq, off = synth.make_motif_reads(genome, 400, 100, seed=seed, amb_rate=0.006, var_len=30)
+        run_case(sdb, odb, seq, off, "hash", 0, "mean")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_long_kmers_and_tree_sizes(seed):
+    """Differential sweep over the corners the small sweep cannot reach: hashed k-mer spaces (DNA k 13..31, amino acids k 5..12),
+    trees from a few branches to the reference's 65 534, mid-size (windowed) and large (indexed, multi-pass) images."""
+    rng = np.random.default_rng(7000 + seed)
+    alphabet = 4 if rng.random() < 0.6 else 20
+    k = int(rng.integers(13, 32)) if alphabet == 4 else int(rng.integers(5, 13))
+    nb = int(rng.choice([3, 250, 999, 2801, 3500, 6000, 11000, 15999, 16001, 25000, 39001, 52000, 65535]))
+    mean_row = float(rng.choice([2.0, 8.0, 40.0, 150.0]))
+    sdb, genome = synth.make_motif_db(k, nb, genome_len=int(rng.integers(300, 2500)), n_variants=int(rng.integers(0, 4)),
+                                      mean_row=mean_row, seed=seed, alphabet=alphabet)
+    odb = O.OracleDB.from_synth(sdb)
+    rl = int(rng.choice([k, k + 1, 60, 150, 290]))
+    seq, off = synth.make_motif_reads(genome, int(rng.integers(1, 500)), rl, seed=seed + 3,
+                                      amb_rate=float(rng.choice([0.0, 0.004, 0.02])), var_len=int(rng.choice([0, rl // 3])))
+    K = int(rng.choice([1, 3, 7, 7, 12, 16]))
+    kw = dict(keepAtMost=K, keepFactor=float(rng.choice([0.0, 0.01, 0.5, 1.0])))
+    run_case(sdb, odb, seq, off, "hash", 0, str(rng.choice(["mean", "max", "skip"])), **kw)
+
+
 def test_long_kmers_large_tree_and_lane_widths():
     sdb, genome = synth.make_motif_db(18, 20001, genome_len=2000, mean_row=150, seed=3)
     odb = O.OracleDB.from_synth(sdb)
