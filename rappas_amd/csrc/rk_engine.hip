@@ -34,6 +34,9 @@ using namespace rk;
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
 #endif
+#ifndef RK_WRING
+#define RK_WRING RK_RING  // the same for the windowed kernel
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -967,11 +970,11 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     if (blocks > n_tiles) blocks = n_tiles;
     if (!blocks) return RK_OK;
     if (db->info.bits_per_symbol == 2) {
-        auto kern = place_packed16w_kernel<2, RK_RING, 9>;
+        auto kern = place_packed16w_kernel<2, RK_WRING, 9>;
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, a);
     } else {
-        auto kern = place_packed16w_kernel<5, RK_RING, 9>;
+        auto kern = place_packed16w_kernel<5, RK_WRING, 9>;
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, a);
     }
@@ -1156,7 +1159,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     }
     if (use_windowed(db, 7, 16)) {
         snprintf(buf, sizeof(buf), "place_packed16w_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches lds/wave=%zuB main=%u work=%u",
-                 db->info.bits_per_symbol, RK_RING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),
+                 db->info.bits_per_symbol, RK_WRING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),
                  db->wp.main_cap, db->wp.work_cap);
         m->kernel_name = buf;
         return m->kernel_name.c_str();

@@ -606,12 +606,115 @@ __device__ __forceinline__ u32 group_max_u32(u32 v) {
     return v;
 }
 
-// Fast select: ONE pass over S.  Every lane keeps its three best (score, slot) pairs in registers plus the fourth-best
-// score (the best it had to drop); K rounds of group-max over the lane heads then give the exact top-K unless some
-// lane might still hide a better entry (it dropped something >= the K-th winner) -- rare (a lane would need >= 4 of
-// the top K); then the exact two-pass scan above runs instead.  A round is two 32-bit reductions: the largest head
-// score, then among the lanes holding it the smallest slot (= the order of the packed key: score desc, branch asc).
-// S is reset with plain 16-byte stores afterwards.
+// Fast select: ONE pass over S.  A lane reads S four consecutive words at a time; word c of every quad feeds the lane's STREAM c,
+// which keeps its two best (score, quad) pairs in registers plus the best score it had to drop.  Slot 4*quad + c belongs to
+// stream c of lane quad % G, so neighbouring branches -- the usual shape of a placement: a clade -- land in different streams.
+// K rounds of group-max over the 4 * G stream heads then give the exact top-K unless some stream might still hide a better
+// entry (it dropped something >= the K-th winner: the stream would need >= 3 of the K best); then the caller runs the exact
+// two-pass scan (select_topk_scan) or its own exact path.  A round is two 32-bit reductions: the largest head score, then
+// among the streams holding it the smallest slot (= the order of the packed key: score desc, branch asc).
+struct Heads4 {
+    float s0[4], s1[4], dr[4];  // per stream: the two best scores (s0 >= s1) and the best dropped one
+    u32 q0[4], q1[4];           // their quads
+};
+__device__ __forceinline__ void heads_clear(Heads4 &h) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        h.s0[c] = h.s1[c] = h.dr[c] = -INFINITY;
+        h.q0[c] = h.q1[c] = 0x3FFFFFFFu;
+    }
+}
+// sorted insertion; strict '>' keeps the smaller slot ahead among equal scores and is false for the -inf marker of untouched
+// branches (one select per statement: nested conditionals came out of hipcc as divergent branches)
+template <int C>
+__device__ __forceinline__ void heads_feed(Heads4 &h, float v, u32 q) {
+    const bool g0 = v > h.s0[C], g1 = v > h.s1[C];
+    const u32 t1 = g1 ? q : h.q1[C];
+    h.q1[C] = g0 ? h.q0[C] : t1;
+    h.q0[C] = g0 ? q : h.q0[C];
+    h.dr[C] = __builtin_amdgcn_fmed3f(v, h.s1[C], h.dr[C]);
+    h.s1[C] = __builtin_amdgcn_fmed3f(v, h.s0[C], h.s1[C]);
+    h.s0[C] = g0 ? v : h.s0[C];
+}
+__device__ __forceinline__ void heads_feed_quad(Heads4 &h, const uint4 v4, u32 q) {
+    heads_feed<0>(h, __uint_as_float(v4.x), q);
+    heads_feed<1>(h, __uint_as_float(v4.y), q);
+    heads_feed<2>(h, __uint_as_float(v4.z), q);
+    heads_feed<3>(h, __uint_as_float(v4.w), q);
+}
+// scans the ns words of S (word 0 = scratch, word i = branch slot_base + i - 1 of the tree; slot_base a multiple of 4) into the
+// heads; the quads are numbered slot_base / 4 + i so that a head's slot is 4 * quad + stream over the whole tree
+template <int G>
+__device__ __forceinline__ void heads_scan(const u32 *S, u32 ns, u32 li, u32 slot_base, Heads4 &h) {
+    const uint4 *S4 = (const uint4 *)S;
+    const u32 n4_full = ns / 4;  // quads that lie entirely below ns need no bounds test
+    const u32 qb = slot_base / 4;
+    if (li < n4_full) {
+        uint4 cur = S4[li];
+        for (u32 q = li; q < n4_full; q += G) {
+            const uint4 v4 = cur;
+            if (q + G < n4_full) cur = S4[q + G];  // next quad is in flight while this one is ranked
+            heads_feed_quad(h, v4, qb + q);
+        }
+    }
+    if ((ns & 3u) && (n4_full % G) == li) {  // the partial last quad
+        uint4 v4 = S4[n4_full];
+        const u32 i = 4 * n4_full;
+        if (i >= ns) v4.x = S_UNTOUCHED;
+        if (i + 1 >= ns) v4.y = S_UNTOUCHED;
+        if (i + 2 >= ns) v4.z = S_UNTOUCHED;
+        if (i + 3 >= ns) v4.w = S_UNTOUCHED;
+        heads_feed_quad(h, v4, qb + n4_full);
+    }
+}
+// K rounds over the 4 * G stream heads; returns numBest, the rank-r key in lane r (0 beyond numBest), and whether a dropped
+// entry could belong to the answer: K ranks filled -- only if it ties or beats the weakest winner; fewer -- any dropped entry.
+// The rounds run on the order-preserving integer image of the scores (integer max folds into the DPP rotate).
+template <int G>
+__device__ __forceinline__ int heads_rounds_raw(const Heads4 &h, int K, u32 li, u32 gi, u32 &win_o, u32 &win_i, bool &doubt) {
+    constexpr u32 ORD_NEG_INF = 0x007FFFFFu;  // ord_f32(-inf)
+    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    u32 o0[4], o1[4], n0[4], n1[4];  // n = ~slot: the smaller slot wins a max
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        o0[c] = ord_f32(h.s0[c]); o1[c] = ord_f32(h.s1[c]);
+        n0[c] = ~(4u * h.q0[c] + (u32)c); n1[c] = ~(4u * h.q1[c] + (u32)c);
+    }
+    u32 last = ORD_NEG_INF;
+    int num = 0;
+    win_o = 0; win_i = 0;  // lane r: ordered score and slot (4 * quad + stream) of rank r
+    for (int r = 0; r < K; r++) {
+        const u32 m = group_max_u32<G>(max(max(o0[0], o0[1]), max(o0[2], o0[3])));
+        const bool valid = m != ORD_NEG_INF;  // group-uniform: something is left
+        u32 cand = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) cand = max(cand, (o0[c] == m) ? n0[c] : 0u);
+        const u32 w = group_max_u32<G>(valid ? cand : 0u);  // smallest slot among the streams holding m
+        const bool mine = (int)li == r && valid;
+        win_o = mine ? m : win_o;
+        win_i = mine ? ~w : win_i;
+        num += valid ? 1 : 0;
+        last = valid ? m : last;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const bool pop = valid && o0[c] == m && n0[c] == w;  // exactly one stream of one lane
+            o0[c] = pop ? o1[c] : o0[c]; n0[c] = pop ? n1[c] : n0[c];
+            o1[c] = pop ? ORD_NEG_INF : o1[c];
+        }
+    }
+    const u32 od = max(max(ord_f32(h.dr[0]), ord_f32(h.dr[1])), max(ord_f32(h.dr[2]), ord_f32(h.dr[3])));
+    const bool d = (num == K) ? (od >= last) : (od != ORD_NEG_INF);
+    doubt = ((__ballot(d) >> (gi * G)) & gmask) != 0;  // group-uniform
+    return num;
+}
+// the same for the slot layout of the packed / ASCII kernels (word 0 of S is the scratch slot, branch x lives in word x + 1)
+template <int G>
+__device__ __forceinline__ int heads_rounds(const Heads4 &h, int K, u32 li, u32 gi, u64 &win_key, bool &doubt) {
+    u32 win_o, win_i;
+    const int num = heads_rounds_raw<G>(h, K, li, gi, win_o, win_i, doubt);
+    win_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
+    return num;
+}
 template <int G>
 __device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key RK_STAMP_PARAMS) {
     // slot layout: the scratch word S[0] leaves the competition, then the scan runs over ns = n_branches + 1 slots and
@@ -620,167 +723,34 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 g
     wave_lds_fence();
     const u32 nb = n_branches + 1;
     if (K > 8) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
-    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
-    const uint4 *S4 = (const uint4 *)S;
+    Heads4 h;
+    heads_clear(h);
+    heads_scan<G>(S, nb, li, 0u, h);
+    RK_STAMP(8);
+    bool doubt;
+    const int num = heads_rounds<G>(h, K, li, gi, win_key, doubt);
+    if (doubt) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
+    RK_STAMP(9);
     uint4 *S4w = (uint4 *)S;
     const u32 n4 = (nb + 3) / 4;
-    float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, s3 = -INFINITY;
-    u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
-    // sorted insertion into the lane's top three (s3 = best dropped score); strict '>' keeps the smaller slot ahead among
-    // equal scores and is false for the -inf marker of untouched branches
-    auto feed = [&](float v, u32 idx) {
-        // (one select per statement: nested conditionals came out of hipcc as divergent branches)
-        const bool g0 = v > s0, g1 = v > s1, g2 = v > s2;
-        const u32 t2 = g2 ? idx : i2;
-        i2 = g1 ? i1 : t2;
-        const u32 t1 = g1 ? idx : i1;
-        i1 = g0 ? i0 : t1;
-        i0 = g0 ? idx : i0;
-        s3 = __builtin_amdgcn_fmed3f(v, s2, s3);
-        s2 = __builtin_amdgcn_fmed3f(v, s1, s2);
-        s1 = __builtin_amdgcn_fmed3f(v, s0, s1);
-        s0 = g0 ? v : s0;
-    };
-    const u32 n4_full = nb / 4;  // quads that lie entirely below nb need no bounds test
-    if (li < n4_full) {
-        uint4 cur = S4[li];
-        for (u32 q = li; q < n4_full; q += G) {
-            const uint4 v4 = cur;
-            if (q + G < n4_full) cur = S4[q + G];  // next quad is in flight while this one is ranked
-            const u32 i = 4 * q;
-            feed(__uint_as_float(v4.x), i);
-            feed(__uint_as_float(v4.y), i + 1);
-            feed(__uint_as_float(v4.z), i + 2);
-            feed(__uint_as_float(v4.w), i + 3);
-        }
-    }
-    if ((nb & 3u) && (n4_full % G) == li) {  // the partial last quad
-        const uint4 v4 = S4[n4_full];
-        const u32 i = 4 * n4_full;
-        feed(i < nb ? __uint_as_float(v4.x) : -INFINITY, i);
-        feed(i + 1 < nb ? __uint_as_float(v4.y) : -INFINITY, i + 1);
-        feed(i + 2 < nb ? __uint_as_float(v4.z) : -INFINITY, i + 2);
-        feed(i + 3 < nb ? __uint_as_float(v4.w) : -INFINITY, i + 3);
-    }
-    RK_STAMP(8);
-    // rounds run on the order-preserving integer image of the scores: integer max folds into the DPP rotate
-    constexpr u32 ORD_NEG_INF = 0x007FFFFFu;  // ord_f32(-inf)
-    u32 o0 = ord_f32(s0), o1 = ord_f32(s1), o2 = ord_f32(s2);
-    u32 win_o = 0, win_i = 0, last = ORD_NEG_INF;
-    int num = 0;
-    for (int r = 0; r < K; r++) {
-        const u32 m = group_max_u32<G>(o0);
-        const bool valid = m != ORD_NEG_INF;  // group-uniform: something is left
-        const bool head = valid && o0 == m;
-        const u32 w = group_max_u32<G>(head ? ~i0 : 0u);  // smallest slot among the lanes holding m
-        const bool pop = head && ~i0 == w;                // exactly one lane
-        const bool mine = (int)li == r && valid;
-        win_o = mine ? m : win_o;
-        win_i = mine ? ~w : win_i;
-        num += valid ? 1 : 0;
-        last = valid ? m : last;
-        o0 = pop ? o1 : o0; i0 = pop ? i1 : i0;
-        o1 = pop ? o2 : o1; i1 = pop ? i2 : i1;
-        o2 = pop ? ORD_NEG_INF : o2; i2 = pop ? 0xFFFFFFFFu : i2;
-    }
-    // could a dropped entry belong to the answer?  K ranks filled: only if it ties or beats the weakest winner;
-    // fewer than K ranks filled: any dropped entry at all
-    const u32 o3 = ord_f32(s3);
-    const bool doubt = (num == K) ? (o3 >= last) : (o3 != ORD_NEG_INF);
-    if (((__ballot(doubt) >> (gi * G)) & gmask) != 0)  // group-uniform
-        return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
-    win_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
-    RK_STAMP(9);
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
     return num;
 }
 
 // ---- the fast select cut in two, for kernels that see the score vector one window at a time (place_packed16w_kernel):
-//      per window the scan feeds a lane's three best (score, global slot) pairs and resets S; the K rounds run once at the end ----
-struct Top3 {
-    float s0, s1, s2, s3;  // three best scores of the lane, and the best one it had to drop
-    u32 i0, i1, i2;        // their slots (tree branch id + 1)
-};
-__device__ __forceinline__ void top3_clear(Top3 &t) {
-    t.s0 = t.s1 = t.s2 = t.s3 = -INFINITY;
-    t.i0 = t.i1 = t.i2 = 0xFFFFFFFFu;
-}
-__device__ __forceinline__ void top3_feed(Top3 &t, float v, u32 idx) {  // (one select per statement: see select_topk)
-    const bool g0 = v > t.s0, g1 = v > t.s1, g2 = v > t.s2;
-    const u32 t2 = g2 ? idx : t.i2;
-    t.i2 = g1 ? t.i1 : t2;
-    const u32 t1 = g1 ? idx : t.i1;
-    t.i1 = g0 ? t.i0 : t1;
-    t.i0 = g0 ? idx : t.i0;
-    t.s3 = __builtin_amdgcn_fmed3f(v, t.s2, t.s3);
-    t.s2 = __builtin_amdgcn_fmed3f(v, t.s1, t.s2);
-    t.s1 = __builtin_amdgcn_fmed3f(v, t.s0, t.s1);
-    t.s0 = g0 ? v : t.s0;
-}
-// scans the n_branches + 1 slots of S (slot 0 = scratch, slot i = branch slot_base + i - 1 of the tree), then resets them
+//      per window the scan feeds the heads and resets S; the K rounds run once at the end ----
 template <int G>
-__device__ __forceinline__ void top3_scan_reset(u32 *S, u32 n_branches, u32 li, u32 slot_base, Top3 &t) {
+__device__ __forceinline__ void heads_scan_reset(u32 *S, u32 n_branches, u32 li, u32 slot_base, Heads4 &h) {
     if (li == 0) S[0] = S_UNTOUCHED;
     wave_lds_fence();
-    const u32 nb = n_branches + 1;
-    const uint4 *S4 = (const uint4 *)S;
-    uint4 *S4w = (uint4 *)S;
-    const u32 n4 = (nb + 3) / 4, n4_full = nb / 4;
-    if (li < n4_full) {
-        uint4 cur = S4[li];
-        for (u32 q = li; q < n4_full; q += G) {
-            const uint4 v4 = cur;
-            if (q + G < n4_full) cur = S4[q + G];
-            const u32 i = slot_base + 4 * q;
-            top3_feed(t, __uint_as_float(v4.x), i);
-            top3_feed(t, __uint_as_float(v4.y), i + 1);
-            top3_feed(t, __uint_as_float(v4.z), i + 2);
-            top3_feed(t, __uint_as_float(v4.w), i + 3);
-        }
-    }
-    if ((nb & 3u) && (n4_full % G) == li) {
-        const uint4 v4 = S4[n4_full];
-        const u32 i = 4 * n4_full;
-        top3_feed(t, i < nb ? __uint_as_float(v4.x) : -INFINITY, slot_base + i);
-        top3_feed(t, i + 1 < nb ? __uint_as_float(v4.y) : -INFINITY, slot_base + i + 1);
-        top3_feed(t, i + 2 < nb ? __uint_as_float(v4.z) : -INFINITY, slot_base + i + 2);
-        top3_feed(t, i + 3 < nb ? __uint_as_float(v4.w) : -INFINITY, slot_base + i + 3);
-    }
+    const u32 ns = n_branches + 1;
+    heads_scan<G>(S, ns, li, slot_base, h);
     wave_lds_fence();
+    uint4 *S4w = (uint4 *)S;
+    const u32 n4 = (ns + 3) / 4;
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
-}
-// K rounds over the lane heads (as in select_topk); returns numBest, the rank-r key in lane r, and whether a dropped entry
-// could belong to the answer (then the caller has to redo the read with the exact select)
-template <int G>
-__device__ __forceinline__ int top3_rounds(const Top3 &t, int K, u32 li, u32 gi, u64 &win_key, bool &doubt) {
-    constexpr u32 ORD_NEG_INF = 0x007FFFFFu;
-    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
-    u32 o0 = ord_f32(t.s0), o1 = ord_f32(t.s1), o2 = ord_f32(t.s2);
-    u32 i0 = t.i0, i1 = t.i1, i2 = t.i2;
-    u32 win_o = 0, win_i = 0, last = ORD_NEG_INF;
-    int num = 0;
-    for (int r = 0; r < K; r++) {
-        const u32 m = group_max_u32<G>(o0);
-        const bool valid = m != ORD_NEG_INF;
-        const bool head = valid && o0 == m;
-        const u32 w = group_max_u32<G>(head ? ~i0 : 0u);
-        const bool pop = head && ~i0 == w;
-        const bool mine = (int)li == r && valid;
-        win_o = mine ? m : win_o;
-        win_i = mine ? ~w : win_i;
-        num += valid ? 1 : 0;
-        last = valid ? m : last;
-        o0 = pop ? o1 : o0; i0 = pop ? i1 : i0;
-        o1 = pop ? o2 : o1; i1 = pop ? i2 : i1;
-        o2 = pop ? ORD_NEG_INF : o2; i2 = pop ? 0xFFFFFFFFu : i2;
-    }
-    const u32 o3 = ord_f32(t.s3);
-    const bool d = (num == K) ? (o3 >= last) : (o3 != ORD_NEG_INF);
-    doubt = ((__ballot(d) >> (gi * G)) & gmask) != 0;
-    win_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
-    return num;
 }
 
 // LWR + keep-factor + output rows for one read.  Called by all lanes of the group (li = lane in group).
@@ -1415,6 +1385,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
     const float T = a.db.T;
     const int K = (int)a.keep_at_most;  // <= 8 (the host picks the dense kernels otherwise)
     const u64 gmask = (1ull << G) - 1;
+    const u64 gmask_mine = gmask << (gi * G);  // this lane's group inside a wave ballot
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     const int main_usable = (int)a.main_cap;
     const int work_usable = (int)a.work_cap - 3 * U - 2;
@@ -1423,6 +1394,9 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
 
     for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
     wave_lds_fence();
+#ifdef RK_STAMPS
+    unsigned long long st_[16] = {0}, t_ = rk_now();
+#endif
 
     const u64 n_tiles = (a.n_reads + NG - 1) / NG;
     const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
@@ -1497,6 +1471,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         if (R < k) flags |= RK_FLAG_TOO_SHORT;
         const u32 Q = mer_count(c_R, fin, have);
         const float QT = (float)(int)Q * T;
+        RK_STAMP(0);  // tile setup
 
         // ---- emit: every row unit of the read -> one tagged item of the main list, k-mer order ----
         int mcnt = 0;
@@ -1539,6 +1514,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         u32 n_recw, n_R, n_fin;
         bool n_have;
         load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
+        RK_STAMP(1);  // probe + emit
 
         // this window's entries of the read applied to S (window w holds the branches [w * W, w * W + win_n))
         auto window_accumulate = [&](u32 w) {
@@ -1552,26 +1528,37 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     const int wcnt = wave_max4(wc);
                     for (int i = wc + (int)li; i < wcnt + 2 * U; i += G) work[i] = ITEM_FILLER;
                     wave_lds_fence();
+                    RK_STAMP(2);  // window compaction
                     if (!(RK_ABLATE & 512)) {
                         if (a.db.mono) accumulate_units<G, U, true, true>(S, work, wcnt, li, rows_rs, QT, T, wlo4p4, w4);
                         else accumulate_units<G, U, false, true>(S, work, wcnt, li, rows_rs, QT, T, wlo4p4, w4);
                     }
                     wave_lds_fence();
+                    RK_STAMP(3);  // window accumulate
+#ifdef RK_STAMPS
+                    st_[10] += (unsigned long long)wcnt; st_[11] += 1; st_[12] += (unsigned long long)wc;
+#endif
                     wc = 0;
                 };
+                // (one item per lane and chunk: ranks inside a group by ballot + mbcnt; the next chunk's items are read ahead so that
+                // a chunk does not wait for its own LDS read; reads past the list stay inside the wave's LDS and are masked out)
                 const int mx = (RK_ABLATE & 2048) ? 0 : wave_max4(mcnt);  // (timing only: no compaction, no accumulate)
+                u32 nxt = mainl[li];
                 for (int base = 0; base < mx; base += G) {
                     const int i = base + (int)li;
-                    const u32 it = i < mcnt ? mainl[i] : 0u;
-                    const u32 f = it & 15u, sp = (it >> 4) & 7u;
-                    const u32 l = sp == 7u ? 15u : f + sp;
-                    const bool sel = i < mcnt && f <= w && w <= l;
-                    const u32 incl = row_scan(sel ? 1u : 0u);
+                    const u32 it = nxt;
+                    nxt = mainl[i + G];
+                    const u32 sp = (it >> 4) & 7u;
+                    const u32 span = ((sp + 1u) & 8u) | sp;  // tag 7 = "to the last window"
+                    const bool sel = (w - (it & 15u)) <= span && i < mcnt;  // unsigned: w below the first window wraps
+                    const u64 mg = __ballot(sel) & gmask_mine;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((u32)(mg >> 32), __builtin_amdgcn_mbcnt_lo((u32)mg, 0u));
                     if (__any(wc + G > work_usable)) flushw();
-                    if (sel) work[wc + (int)incl - 1] = it & ~127u;
-                    wc += (int)row_bcast32<15>(incl);
+                    if (sel) work[wc + rank] = it & ~127u;
+                    wc += __builtin_popcount((u32)mg) + __builtin_popcount((u32)(mg >> 32));
                 }
                 if (__any(wc > 0)) flushw();
+                RK_STAMP(2);
             } else {
                 // ---- fallback: probe the read again for this window; rows that touch it go through the row cursor ----
                 int rc = 0;
@@ -1602,24 +1589,23 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 flush_rows();
             }
         };
-        // fast pass: every window is scanned into the lanes' three best entries and reset; the K rounds run once, over the whole
-        // tree.  If an entry a lane had to drop could still belong to the answer (rare: a lane would need >= 4 of the K best),
+        // fast pass: every window is scanned into the stream heads (select_topk) and reset; the K rounds run once, over the whole
+        // tree.  If an entry a stream had to drop could still belong to the answer (rare: a stream would need >= 3 of the K best),
         // the tile is redone with the exact select of every window and a merge of the windows' K best.
         u64 acc_key = 0;  // lane r < K: rank-r key (low 16 bits: 0xFFFF - tree branch id)
         bool doubt = false;
-#ifdef RK_STAMPS
-        unsigned long long st_[16] = {0}, t_ = 0;  // (no phase stamps in this kernel; select_topk wants the pair)
-#endif
         {
-            Top3 t3;
-            top3_clear(t3);
+            Heads4 hd;
+            heads_clear(hd);
             for (u32 w = 0; w < NWIN; w++) {
                 window_accumulate(w);
                 const u32 wlo = w * W;
-                top3_scan_reset<G>(S, nb - wlo < W ? nb - wlo : W, li, wlo, t3);
+                heads_scan_reset<G>(S, nb - wlo < W ? nb - wlo : W, li, wlo, hd);
                 wave_lds_fence();
+                RK_STAMP(4);  // window scan + reset
             }
-            top3_rounds<G>(t3, K, li, gi, acc_key, doubt);
+            heads_rounds<G>(hd, K, li, gi, acc_key, doubt);
+            RK_STAMP(5);  // rounds
         }
         if (__any(doubt)) {
             acc_key = 0;
@@ -1645,9 +1631,15 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         }
         const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+        RK_STAMP(6);  // redo of tiles in doubt
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
         c_recw = n_recw; c_R = n_R; c_fin = n_fin; c_have = n_have;
+        RK_STAMP(7);  // weigh + store
     }
+#ifdef RK_STAMPS
+    if (lane == 0 && wave_global < 4096)
+        for (int i = 0; i < 16; i++) rk_stamp_buf[wave_global * 16 + i] = st_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1852,43 +1844,24 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                 __syncthreads();
             }
 
-            // ---- select, level 1: every wave ranks its segment of S (three best per lane, K rounds of wave max) ----
-            float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY, lost = -INFINITY;
-            u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
-            auto feed = [&](float v, u32 idx, bool in) {
-                const bool g0 = in && v > s0, g1 = in && v > s1, g2 = in && v > s2;
-                const float drop = g2 ? s2 : (in ? v : -INFINITY);
-                lost = fmaxf(lost, drop);
-                s2 = g1 ? s1 : (g2 ? v : s2);
-                i2 = g1 ? i1 : (g2 ? idx : i2);
-                s1 = g0 ? s0 : (g1 ? v : s1);
-                i1 = g0 ? i0 : (g1 ? idx : i1);
-                s0 = g0 ? v : s0;
-                i0 = g0 ? idx : i0;
-            };
+            // ---- select, level 1: every wave ranks its segment of S (stream heads as in select_topk, K rounds of wave max) ----
+            Heads4 hd;
+            heads_clear(hd);
             for (u32 q = sq0 + lane; q < sq1; q += 64) {
-                const uint4 v4 = S4[q];
-                const u32 i = 4 * q;
-                const bool full = q < n4_full;
-                feed(__uint_as_float(v4.x), i, full || i < win);
-                feed(__uint_as_float(v4.y), i + 1, full || i + 1 < win);
-                feed(__uint_as_float(v4.z), i + 2, full || i + 2 < win);
-                feed(__uint_as_float(v4.w), i + 3, full || i + 3 < win);
+                uint4 v4 = S4[q];
+                if (q >= n4_full) {  // the partial last quad of the window
+                    const u32 i = 4 * q;
+                    if (i >= win) v4.x = S_UNTOUCHED;
+                    if (i + 1 >= win) v4.y = S_UNTOUCHED;
+                    if (i + 2 >= win) v4.z = S_UNTOUCHED;
+                    if (i + 3 >= win) v4.w = S_UNTOUCHED;
+                }
+                heads_feed_quad(hd, v4, q);
             }
-            u64 k0 = (i0 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s0), i0 + base) : 0ull;
-            u64 k1 = (i1 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s1), i1 + base) : 0ull;
-            u64 k2 = (i2 != 0xFFFFFFFFu) ? make_key(__float_as_uint(s2), i2 + base) : 0ull;
-            u64 wkey = 0, last = 0;
-            int num = 0;
-            for (int rr = 0; rr < K; rr++) {
-                const u64 mx = group_max<64>(k0);
-                if (mx == 0) break;
-                num++;
-                last = mx;
-                if (k0 == mx) { k0 = k1; k1 = k2; k2 = 0; }
-                if ((int)lane == rr) wkey = mx;
-            }
-            const bool doubt = (num == K) ? (lost >= unord_f32((u32)(last >> 32))) : (lost > -INFINITY);
+            u32 win_o, win_i;
+            bool doubt;
+            int num = heads_rounds_raw<64>(hd, K, lane, 0u, win_o, win_i, doubt);
+            u64 wkey = ((int)lane < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i + base))) : 0ull;
             if (__any(doubt)) num = select_rounds64(S, win, base, sq0, sq1, lane, K, wkey);
             for (u32 q = sq0 + lane; q < sq1; q += 64) S4w[q] = reset4;
             if ((int)lane < K) cand[(pass * NW + wave) * K + lane] = ((int)lane < num) ? wkey : 0ull;

@@ -6,6 +6,7 @@ so = os.path.join(ROOT, "rappas_amd", "variants", "librk_stamps.so")
 extra = sys.argv[1:]
 flags = [a for a in extra if a.startswith("-D")]
 table = next((a.split("=")[1] for a in extra if a.startswith("--table=")), "auto")
+branches = int(next((a.split("=")[1] for a in extra if a.startswith("--branches=")), "0"))  # mid-size tree (windowed kernel) instead of C2
 if flags or not os.path.exists(so):  # (prebuild it on the build host into rappas_amd/variants/ to save GPU-box time)
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DRK_STAMPS"] + flags +
@@ -14,7 +15,7 @@ os.environ["RK_LIB"] = so
 import numpy as np, torch
 import rappas_amd as ra
 from rappas_amd import synth
-sdb = synth.make_config_db("C2")
+sdb = synth.make_db(4, 10, branches, 786432, 10_000_000, seed=42) if branches else synth.make_config_db("C2")
 mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": ra.RK_TABLE_HASH}[table]
 db = ra.PhyloKmerDB.from_synth(sdb, table_mode=mode)
 pp = ra.PlacementProcess(db)
@@ -33,10 +34,19 @@ a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 16).astype(np.float64)
 tot = a.sum(1)
 names = ["tile setup", "probe (codes+gathers)", "scan+emit items", "pre-accumulate fence", "accumulate", "select (rest: reset)", "weigh+store", "-",
          "select: scan", "select: rounds"]
+windowed = "packed16w" in db.kernel_name()
+if windowed:
+    names = ["tile setup", "probe + emit", "window compaction", "window accumulate", "window scan + reset", "rounds", "redo (doubt)", "weigh+store"]
 a = a[tot > 0]
 tot = tot[tot > 0]
 nw = len(tot)
 print(db.kernel_name())
 print("median wave cycles:", np.median(tot), " per tile:", np.median(tot) / (n / 4 / nw))
+if windowed:
+    tot = a[:, :10].sum(1)
 for i, nm in enumerate(names):
     print(f"  {nm:24s} {100 * np.median(a[:, i] / tot):5.1f} %   {np.median(a[:, i]) / (n / 4 / nw):8.0f} cycles/tile")
+if windowed:
+    tiles = n / 4 / nw
+    print(f"  accumulate calls/tile {np.median(a[:, 11]) / tiles:.2f}, steps/call {np.median(a[:, 10] / a[:, 11]):.1f}, "
+          f"cycles/call {np.median(a[:, 3] / a[:, 11]):.0f}, cycles/step {np.median(a[:, 3] / a[:, 10]):.1f}")
