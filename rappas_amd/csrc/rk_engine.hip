@@ -29,7 +29,7 @@ using namespace rk;
 #define RK_WG_ALWAYS_BRANCHES 16000u  // ... or, whatever the rows, above this many branches
 #endif
 #ifndef RK_WINDOW_MIN_BRANCHES
-#define RK_WINDOW_MIN_BRANCHES 2800u  // below this the dense 32-lane geometry (>= 6 waves per CU) is ahead of the windowed kernel (scripts/tree_size_sweep.py)
+#define RK_WINDOW_MIN_BRANCHES 1116u  // up to here the dense 16-lane geometry keeps eight waves per CU; beyond it the windowed kernel is ahead (scripts/tree_size_sweep.py: 1 300 branches 241 against 219 Mreads/s, 2 800: 185 against 141)
 #endif
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
@@ -70,6 +70,21 @@ int fail_msg(int code, const char *fmt, ...) {  // rk_internal.h: the same sink 
     } while (0)
 
 extern "C" const char *rk_last_error(void) { return g_err; }
+
+// The placement kernels are launched as persistent grids: one block per slot a CU really has, every block walking the batch with
+// the grid's stride.  The slots are what the runtime says fit (registers, the LDS allocation granule), not LDS size / LDS
+// per block: a grid one block per CU too large runs a second round and costs up to 2 x (seen: 23 360 B of LDS per block, seven
+// by division, six resident; 32-lane geometry with 11 by division, 8 by registers).
+template <typename K>
+static int resident_blocks(K kern, int block_threads, size_t lds, uint64_t by_lds, uint64_t &out) {
+    int n = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, block_threads, lds));
+    if (n < 1) return fail(RK_ERR_UNSUPPORTED, "internal: kernel does not fit a CU (%d threads, %zu B of LDS per block)", block_threads, lds);
+    out = by_lds < (uint64_t)n ? by_lds : (uint64_t)n;
+    static const bool trace = getenv("RK_TRACE_GRID") != nullptr;  // developer knob
+    if (trace) fprintf(stderr, "[rk] grid: %d threads, %zu B LDS per block -> %d resident per CU (by LDS size %llu)\n", block_threads, lds, n, (unsigned long long)by_lds);
+    return RK_OK;
+}
 extern "C" int rk_version(void) { return RK_VERSION; }
 
 // Main_DBBUILD_3.java:165-166
@@ -213,15 +228,17 @@ struct WindowPlan {
 // (4-bit window ids in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
 static bool window_plan(uint32_t nb, WindowPlan &wp) {
     if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
-    const uint32_t per_group_words = 160 * 1024 / 8 / 4 / 4;  // 1280 u32 words per read
     uint32_t n_win = (nb + 895) / 896;
     if (n_win > 16) n_win = 16;
     wp.n_win = n_win;
     wp.W = ((nb + n_win - 1) / n_win + 3) & ~3u;
     wp.s_stride = wp.W + 4;
+    const uint32_t per_group_words = 160 * 1024 / 8 / 4 / 4;  // 1280 u32 words per read = eight waves per CU
     // the main list has to hold a whole read (C2-like reads: 145 row units on average, 250 at the tail); what is left goes to the
     // per-window work list, so that a window is normally applied in one accumulate call (each call pays a pipeline fill)
     const uint32_t avail = per_group_words - wp.s_stride;
+    // (88 words = the 44 keys the exact select of a window needs as scratch; seven waves per CU with a 256-item main list were
+    // tried for the 16 x 1 000-branch windows: 61 against 71 Mreads/s)
     uint32_t work = avail > 256 + 88 ? avail - 256 : 88;
     if (work > 200) work = 200;
     wp.work_cap = work & ~1u;
@@ -871,10 +888,12 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
     if (G == 0) {
         // Throughput follows the reads in flight per CU (LDS capacity / score-vector size) and, at equal reads in flight, prefers
         // narrower groups as long as enough waves remain to hide latency.  Measured on C2-like DBs (scripts/tree_size_sweep.py):
-        // 999 branches: 16 lanes (8 waves) 323 Mreads/s; 1999: 32 lanes (8 waves) 185 vs 16 lanes (4 waves) 132 vs 64 lanes 112;
-        // 3999: 32 lanes (4 waves) 88 vs 64 lanes (9 waves) 62; 7999: 64 lanes (4 waves) 46 vs 32 lanes (2 waves) 35.
+        // 999 branches: 16 lanes (8 waves) 335 Mreads/s; 1300 / 1500: 16 lanes (6 waves) 219 / 214 vs 32 lanes (11 / 10 waves) 156 / 141;
+        // 1999: 32 lanes (8 waves) 199 vs 16 lanes (4 waves) 165 vs 64 lanes 120; 3999: 32 lanes (4 waves) 88 vs 64 lanes (9 waves) 62;
+        // 7999: 64 lanes (4 waves) 46 vs 32 lanes (2 waves) 35.  (Between 1 117 and 16 000 branches these dense geometries only serve
+        // what the windowed kernel does not take: keep_at_most > 8, records of more than 16 words, a forced lane width.)
         G = 64;
-        if (keep_at_most <= 16 && bytes_for(16, 16 + 3 * RK_RING + 40) <= db->lds_per_cu / 8) G = 16;
+        if (keep_at_most <= 16 && bytes_for(16, 16 + 3 * RK_RING + 40) <= db->lds_per_cu / 6) G = 16;
         else if (keep_at_most <= 32 && bytes_for(32, 32 + 3 * RK_RING + 40) <= db->lds_per_cu / 4) G = 32;
     }
     if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
@@ -924,7 +943,9 @@ static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &a
     const size_t lds = g.lds_per_wave * wpb;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t n_tiles = (args.n_reads + g.NG - 1) / g.NG;
-    uint64_t blocks = (uint64_t)db->cu_count * ((g.waves_per_cu + wpb - 1) / wpb);
+    uint64_t per_cu = 0;
+    if (int rc = resident_blocks(kern, 64 * (int)wpb, lds, (g.waves_per_cu + wpb - 1) / wpb, per_cu)) return rc;
+    uint64_t blocks = (uint64_t)db->cu_count * per_cu;
     const uint64_t need = (n_tiles + wpb - 1) / wpb;
     if (blocks > need) blocks = need;
     if (blocks == 0) return RK_OK;
@@ -966,18 +987,17 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     if (waves_cu < 1) return fail(RK_ERR_UNSUPPORTED, "internal: windowed geometry does not fit the LDS");
     if (waves_cu > 8) waves_cu = 8;  // two waves per SIMD: the kernel's register budget
     const uint64_t n_tiles = (a.n_reads + 3) / 4;
-    uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
-    if (blocks > n_tiles) blocks = n_tiles;
-    if (!blocks) return RK_OK;
-    if (db->info.bits_per_symbol == 2) {
-        auto kern = place_packed16w_kernel<2, RK_WRING, 9>;
+    if (!n_tiles) return RK_OK;
+    auto launch = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+        uint64_t per_cu = 0;
+        if (int rc = resident_blocks(kern, 64, lds_wave, waves_cu, per_cu)) return rc;
+        uint64_t blocks = (uint64_t)db->cu_count * per_cu;
+        if (blocks > n_tiles) blocks = n_tiles;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, a);
-    } else {
-        auto kern = place_packed16w_kernel<5, RK_WRING, 9>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, a);
-    }
+        return RK_OK;
+    };
+    if (int rc = db->info.bits_per_symbol == 2 ? launch(place_packed16w_kernel<2, RK_WRING, 9>) : launch(place_packed16w_kernel<5, RK_WRING, 9>)) return rc;
     HIP_TRY(hipGetLastError());
     return RK_OK;
 }
@@ -1051,18 +1071,17 @@ static int launch_wg_v(const rk_db *db, const WgGeometry &g, PlaceArgs a, hipStr
     a.s_stride = g.s_stride;
     a.list_cap = g.list_cap;
     a.n_pass = g.n_pass;
-    uint64_t blocks = (uint64_t)db->cu_count * g.wgs_per_cu;
-    if (blocks > a.n_reads) blocks = a.n_reads;
-    if (!blocks) return RK_OK;
-    if (db->info.rows_bytes < ROWS_FIT32_LIMIT) {
-        auto kern = place_wg_kernel<BITS, TM, false, RK_RING>;
+    if (!a.n_reads) return RK_OK;
+    auto launch = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        uint64_t per_cu = 0;
+        if (int rc = resident_blocks(kern, 64 * (int)g.nw, g.lds, g.wgs_per_cu, per_cu)) return rc;
+        uint64_t blocks = (uint64_t)db->cu_count * per_cu;
+        if (blocks > a.n_reads) blocks = a.n_reads;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * g.nw), g.lds, stream, a);
-    } else {
-        auto kern = place_wg_kernel<BITS, TM, true, RK_RING>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * g.nw), g.lds, stream, a);
-    }
+        return RK_OK;
+    };
+    if (int rc = db->info.rows_bytes < ROWS_FIT32_LIMIT ? launch(place_wg_kernel<BITS, TM, false, RK_RING>) : launch(place_wg_kernel<BITS, TM, true, RK_RING>)) return rc;
     HIP_TRY(hipGetLastError());
     return RK_OK;
 }
@@ -1110,18 +1129,17 @@ static int launch_ascii_v(const rk_db *db, PlaceArgs args, AmbArgs m, hipStream_
     const uint64_t groups = (args.n_reads + 63) / 64;
     uint64_t waves_cu = db->lds_per_cu / lds;
     if (waves_cu > 32) waves_cu = 32;
-    uint64_t blocks = (uint64_t)db->cu_count * waves_cu;
-    if (blocks > groups) blocks = groups;
-    if (!blocks) return RK_OK;
-    if (db->indexed) {
-        auto kern = place_ascii_kernel<BITS, TM, true>;
+    if (!groups) return RK_OK;
+    auto launch = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        uint64_t per_cu = 0;
+        if (int rc = resident_blocks(kern, 64, lds, waves_cu, per_cu)) return rc;
+        uint64_t blocks = (uint64_t)db->cu_count * per_cu;
+        if (blocks > groups) blocks = groups;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
-    } else {
-        auto kern = place_ascii_kernel<BITS, TM, false>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, stream, args, m);
-    }
+        return RK_OK;
+    };
+    if (int rc = db->indexed ? launch(place_ascii_kernel<BITS, TM, true>) : launch(place_ascii_kernel<BITS, TM, false>)) return rc;
     HIP_TRY(hipGetLastError());
     return RK_OK;
 }

@@ -644,9 +644,11 @@ __device__ __forceinline__ void heads_feed_quad(Heads4 &h, const uint4 v4, u32 q
 }
 // scans the ns words of S (word 0 = scratch, word i = branch slot_base + i - 1 of the tree; slot_base a multiple of 4) into the
 // heads; the quads are numbered slot_base / 4 + i so that a head's slot is 4 * quad + stream over the whole tree
-template <int G>
-__device__ __forceinline__ void heads_scan(const u32 *S, u32 ns, u32 li, u32 slot_base, Heads4 &h) {
-    const uint4 *S4 = (const uint4 *)S;
+// RESET: every quad is set back to UNTOUCHED right behind its read (for callers that never need S again)
+template <int G, bool RESET = false>
+__device__ __forceinline__ void heads_scan(u32 *S, u32 ns, u32 li, u32 slot_base, Heads4 &h) {
+    uint4 *S4 = (uint4 *)S;
+    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     const u32 n4_full = ns / 4;  // quads that lie entirely below ns need no bounds test
     const u32 qb = slot_base / 4;
     if (li < n4_full) {
@@ -654,11 +656,13 @@ __device__ __forceinline__ void heads_scan(const u32 *S, u32 ns, u32 li, u32 slo
         for (u32 q = li; q < n4_full; q += G) {
             const uint4 v4 = cur;
             if (q + G < n4_full) cur = S4[q + G];  // next quad is in flight while this one is ranked
+            if (RESET) S4[q] = reset4;
             heads_feed_quad(h, v4, qb + q);
         }
     }
     if ((ns & 3u) && (n4_full % G) == li) {  // the partial last quad
         uint4 v4 = S4[n4_full];
+        if (RESET) S4[n4_full] = reset4;
         const u32 i = 4 * n4_full;
         if (i >= ns) v4.x = S_UNTOUCHED;
         if (i + 1 >= ns) v4.y = S_UNTOUCHED;
@@ -744,13 +748,7 @@ template <int G>
 __device__ __forceinline__ void heads_scan_reset(u32 *S, u32 n_branches, u32 li, u32 slot_base, Heads4 &h) {
     if (li == 0) S[0] = S_UNTOUCHED;
     wave_lds_fence();
-    const u32 ns = n_branches + 1;
-    heads_scan<G>(S, ns, li, slot_base, h);
-    wave_lds_fence();
-    uint4 *S4w = (uint4 *)S;
-    const u32 n4 = (ns + 3) / 4;
-    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
-    for (u32 q = li; q < n4; q += G) S4w[q] = reset4;
+    heads_scan<G, true>(S, n_branches + 1, li, slot_base, h);  // (a tile in doubt is accumulated again from its lists, not from S)
 }
 
 // LWR + keep-factor + output rows for one read.  Called by all lanes of the group (li = lane in group).

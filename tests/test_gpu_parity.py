@@ -598,7 +598,7 @@ def _scatter_rows(sdb, seed):
     return synth.SynthDB(sdb.alphabet, sdb.k, sdb.n_branches, sdb.thr, sdb.thr_log10, sdb.key_codes, sdb.row_offsets, br, sdb.scores, sdb.seed)
 
 
-@pytest.mark.parametrize("n_branches", [2801, 3999, 7999, 15999])
+@pytest.mark.parametrize("n_branches", [1117, 1500, 2801, 3999, 7999, 15999])
 @pytest.mark.parametrize("amb", ["mean", "skip"])
 def test_mid_size_trees_take_the_windowed_kernel(n_branches, amb):
     sdb = synth.make_db(4, 8, n_branches, 40000, 520000, seed=n_branches)
@@ -609,6 +609,49 @@ def test_mid_size_trees_take_the_windowed_kernel(n_branches, amb):
     db.close()
     _, _, st = run_case(sdb, odb, seq, off, "direct", 0, amb)
     assert st["placed"] > 2500
+
+
+def _clade_db(k, n_branches, genome_len, seed, mean_row=12.0, jitter=5):
+    """keys = the k-mers of a random genome; the rows of the k-mers of one 500-bp stretch cover the same few dozen branches: reads cut
+    from the genome pile their hits on one neighbourhood, so the K best branches are adjacent ids (a clade)"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=genome_len).astype(np.uint64)
+    codes = np.zeros(genome_len - k + 1, dtype=np.uint64)
+    for i in range(k):
+        codes += g[i:genome_len - k + 1 + i] << np.uint64(2 * i)
+    key_codes, pos = np.unique(codes, return_index=True)
+    order = rng.permutation(len(key_codes))
+    key_codes, pos = key_codes[order], pos[order]
+    lens = np.minimum(rng.geometric(1.0 / mean_row, size=len(key_codes)), n_branches - 1).astype(np.int64)
+    off = np.zeros(len(key_codes) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    hi = np.maximum(1, n_branches - lens)
+    block = pos // 500  # 500-bp stretches of the genome share a neighbourhood of the tree
+    b0 = np.clip(1 + block * np.maximum(1, hi - 40) // (genome_len // 500 + 1) + rng.integers(-jitter, jitter + 1, size=len(pos)), 1, hi)
+    total = int(off[-1])
+    within = np.arange(total, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
+    branch = (np.repeat(b0, lens) + within).astype(np.uint16)
+    thr, thr_log10 = synth.thresholds(1.5, 4, k)
+    scores = (thr_log10 * rng.random(total, dtype=np.float32)).astype(np.float32)
+    return synth.SynthDB(4, k, n_branches, thr, thr_log10, key_codes, off, branch, scores, seed), "".join("ATCG"[int(b)] for b in g)
+
+
+@pytest.mark.parametrize("n_branches", [999, 3999, 9001, 20001])
+@pytest.mark.parametrize("K", [3, 7, 8])
+def test_best_branches_that_are_neighbours(n_branches, K):
+    """the K best branches of every read are adjacent ids: the stream heads of the fast select must keep them apart (and the exact
+    paths behind it must agree when a stream has to drop one)"""
+    sdb, genome = _clade_db(9, n_branches, 6000, seed=n_branches + K)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_motif_reads(genome, 2000, 150, seed=K, amb_rate=0.001, var_len=30)
+    got, ref, st = run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0)
+    assert st["placed"] == 2000
+    br = ref["branch"][:, :K].astype(np.int64)
+    full = ref["n_rows"] >= K
+    assert full.sum() > 1500 and np.median((br.max(1) - br.min(1))[full]) < 4 * K  # really neighbours
+    for lanes in (16, 64):
+        if n_branches <= 9001:
+            run_case(sdb, odb, seq, off, "direct", lanes, "mean", keepAtMost=K, keepFactor=0.0)
 
 
 def test_windowed_kernel_rows_scattered_over_all_windows():
