@@ -980,7 +980,11 @@ static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_
 }
 
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
-    const WindowPlan &wp = db->wp;
+    WindowPlan wp = db->wp;
+    if (a.words_per_read > 10 && wp.work_cap > 88) {  // reads beyond ~160 bases: a whole read in the main list matters more than one accumulate call per window
+        wp.main_cap += wp.work_cap - 88;
+        wp.work_cap = 88;
+    }
     a.s_stride = wp.s_stride; a.main_cap = wp.main_cap; a.work_cap = wp.work_cap; a.list_cap = wp.work_cap / 2;
     const size_t lds_wave = (size_t)4 * (wp.s_stride + wp.main_cap + wp.work_cap) * 4;
     uint32_t waves_cu = (uint32_t)(db->lds_per_cu / lds_wave);
