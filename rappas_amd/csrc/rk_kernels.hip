@@ -22,7 +22,7 @@
 #define RK_ROW_NT 0
 #endif
 #ifndef RK_ABLATE
-#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate, 512 / 1024 / 2048 = windowed kernel without accumulate / with the exact select only in the last window / without compaction and accumulate (outputs are then wrong)
+#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate, 512 / 1024 / 2048 = windowed kernel without accumulate / with the exact select only in the last window / without compaction and accumulate (outputs are then wrong), 4096 = windowed kernel without skipping untouched windows (outputs stay right)
 #endif
 #include "../../include/rappas_place.h"
 
@@ -1471,48 +1471,60 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         const float QT = (float)(int)Q * T;
         RK_STAMP(0);  // tile setup
 
-        // ---- emit: every row unit of the read -> one tagged item of the main list, k-mer order ----
+        // ---- emit: every row unit of the read whose row reaches a window of [wa, wb) -> one tagged item of the main list, k-mer
+        //      order.  Called with all windows first; if some read of the tile does not fit its main list the window range is cut
+        //      in two and each half emitted on its own (a row's items count in every half its span reaches); a half that still
+        //      does not fit takes the per-window probe of window_accumulate ----
         int mcnt = 0;
         bool overflow = false;  // wave-uniform: some read of the tile does not fit its main list
-        auto emit_tagged = [&](const u64 (&desc)[PU], const u32 (&ws)[PU], bool more) {
-            u32 nch[PU], excl[PU];
-            int total = 0;
+        u32 touched = 0;        // windows some row of this lane's k-mers reaches (bit w), from the first call
+        auto emit_range = [&](u32 wa, u32 wb) {
+            mcnt = 0;
+            overflow = false;
+            const u32 range = (1u << wb) - (1u << wa);
+            for (u32 pos = 0; __any(pos < Q); pos += PU * G) {
+                u64 code[PU], desc[PU];
+                RawSlot raw[PU];
+                u32 ws[PU];
+                fetch_batch(c_recw, pos, Q, code, raw, ws);
+                __builtin_amdgcn_sched_barrier(0);
+                decode_batch(code, raw, pos, Q, desc);
+                u32 nch[PU], excl[PU];
+                int total = 0;
 #pragma unroll
-            for (int u = 0; u < PU; u++) {
-                nch[u] = (((u32)desc[u] & DESC_LEN_MASK) + G - 1) >> 4;  // <= 255 units (compact table)
-                const u32 incl = row_scan(nch[u]);
-                excl[u] = (u32)total + incl - nch[u];
-                total += (int)row_bcast32<15>(incl);
-            }
-            if (__any(more && mcnt + total > main_usable)) { overflow = true; return; }
+                for (int u = 0; u < PU; u++) {
+                    const u32 f = ws[u] & 15u, l0 = f + (ws[u] >> 4), l = l0 < 15u ? l0 : 15u;
+                    const u32 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (2u << l) - (1u << f) : 0u;
+                    touched |= span;
+                    nch[u] = (span & range) ? (((u32)desc[u] & DESC_LEN_MASK) + G - 1) >> 4 : 0u;  // <= 255 units (compact table)
+                }
+                if (overflow) continue;  // (the rest of the read is probed for its spans alone)
 #pragma unroll
-            for (int u = 0; u < PU; u++) {
-                const u32 sp = ws[u] >> 4;
-                const u32 tag = (ws[u] & 15u) | ((sp < 7u ? sp : 7u) << 4);
-                const u32 rb = (u32)(desc[u] >> DESC_LEN_BITS) * 8u;
-                const int base = mcnt + (int)excl[u];
-                if (nch[u] > 0) mainl[base] = rb | tag;
-                if (nch[u] > 1) mainl[base + 1] = (rb + 128u) | tag;
-                for (u32 c = 2; __any(c < nch[u]); c++)
-                    if (c < nch[u]) mainl[base + (int)c] = (rb + c * 128u) | tag;
+                for (int u = 0; u < PU; u++) {
+                    const u32 incl = row_scan(nch[u]);
+                    excl[u] = (u32)total + incl - nch[u];
+                    total += (int)row_bcast32<15>(incl);
+                }
+                if (__any(pos < Q && mcnt + total > main_usable)) { overflow = true; continue; }
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const u32 sp = ws[u] >> 4;
+                    const u32 tag = (ws[u] & 15u) | ((sp < 7u ? sp : 7u) << 4);
+                    const u32 rb = (u32)(desc[u] >> DESC_LEN_BITS) * 8u;
+                    const int base = mcnt + (int)excl[u];
+                    if (nch[u] > 0) mainl[base] = rb | tag;
+                    if (nch[u] > 1) mainl[base + 1] = (rb + 128u) | tag;
+                    for (u32 c = 2; __any(c < nch[u]); c++)
+                        if (c < nch[u]) mainl[base + (int)c] = (rb + c * 128u) | tag;
+                }
+                mcnt += total;
             }
-            mcnt += total;
+            wave_lds_fence();
         };
-        for (u32 pos = 0; !overflow && __any(pos < Q); pos += PU * G) {
-            u64 code[PU], desc[PU];
-            RawSlot raw[PU];
-            u32 ws[PU];
-            fetch_batch(c_recw, pos, Q, code, raw, ws);
-            __builtin_amdgcn_sched_barrier(0);
-            decode_batch(code, raw, pos, Q, desc);
-            emit_tagged(desc, ws, pos < Q);
-        }
-        wave_lds_fence();
-        // next tile's inputs: in flight during this tile's window passes
-        u32 n_recw, n_R, n_fin;
-        bool n_have;
-        load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
-        RK_STAMP(1);  // probe + emit
+        u32 n_recw = 0, n_R = 0, n_fin = 0;  // next tile's inputs: loaded after the first emit, in flight during the window passes
+        bool n_have = false;
+        u32 tile_windows = 0xFFFFu;
+        bool split = false;  // wave-uniform: the tile did not fit whole, its windows run in two halves
 
         // this window's entries of the read applied to S (window w holds the branches [w * W, w * W + win_n))
         auto window_accumulate = [&](u32 w) {
@@ -1587,44 +1599,73 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 flush_rows();
             }
         };
-        // fast pass: every window is scanned into the stream heads (select_topk) and reset; the K rounds run once, over the whole
-        // tree.  If an entry a stream had to drop could still belong to the answer (rare: a stream would need >= 3 of the K best),
-        // the tile is redone with the exact select of every window and a merge of the windows' K best.
+        // Phase 0, the fast pass: every window the tile reaches is accumulated, scanned into the stream heads (select_topk) and
+        // reset; the K rounds run once, over the whole tree.  Phase 1, only if an entry a stream had to drop could still belong to
+        // the answer (a stream would need >= 3 of the K best): the tile again, with the exact select of every window and a merge of
+        // the windows' K best.  Windows no read of the tile reaches are skipped whole (their S is in its reset state): reads of one
+        // clade fill one or two of up to sixteen windows.  (One loop over phases and halves so that the emit, the window pass and
+        // the two selects exist once in the code: the copies an unrolled structure makes cost registers.)
         u64 acc_key = 0;  // lane r < K: rank-r key (low 16 bits: 0xFFFF - tree branch id)
         bool doubt = false;
-        {
-            Heads4 hd;
-            heads_clear(hd);
-            for (u32 w = 0; w < NWIN; w++) {
-                window_accumulate(w);
-                const u32 wlo = w * W;
-                heads_scan_reset<G>(S, nb - wlo < W ? nb - wlo : W, li, wlo, hd);
-                wave_lds_fence();
-                RK_STAMP(4);  // window scan + reset
+        Heads4 hd;
+        heads_clear(hd);
+        bool first = true;
+        for (int phase = 0; phase < 2; phase++) {
+            if (phase == 1) {
+                if (!__any(doubt)) break;
+                acc_key = 0;
             }
-            heads_rounds<G>(hd, K, li, gi, acc_key, doubt);
-            RK_STAMP(5);  // rounds
-        }
-        if (__any(doubt)) {
-            acc_key = 0;
-            for (u32 w = 0; w < NWIN; w++) {
-                window_accumulate(w);
-                const u32 wlo = w * W;
-                const u32 win_n = nb - wlo < W ? nb - wlo : W;
-            // ---- select over the window, merged into the K best so far ----
-            u64 win_key = 0;
-            if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key RK_STAMP_ARGS);  // (timing only)
-            wave_lds_fence();
-            if (win_key != 0ull) win_key -= (u64)wlo;  // window-relative branch -> tree id (low 16 bits hold 0xFFFF - branch)
-            const u64 moved = ((u64)row_ror32<8>((u32)(win_key >> 32)) << 32) | row_ror32<8>((u32)win_key);  // lane r -> lane r + 8
-            const u64 comb = li < 8 ? acc_key : moved;
-            const int rank = RankAbove<G, G - 1>::run(comb, li);
-            work64[li] = 0ull;
-            wave_lds_fence();
-            if (comb != 0ull && rank < K) work64[rank] = comb;
-            wave_lds_fence();
-            acc_key = (int)li < K ? work64[li] : 0ull;
-            wave_lds_fence();
+            for (u32 part = 0; part < (split ? 2u : 1u); part++) {
+                const u32 h = NWIN / 2;
+                const u32 wa = (split && part) ? h : 0u, wb = (split && !part) ? h : NWIN;
+                if (split && !((tile_windows >> wa) & ((1u << (wb - wa)) - 1u))) continue;  // nothing in this half
+                if (first || split) emit_range(wa, wb);  // (the exact pass of an unsplit tile finds its main list as the fast pass left it)
+                if (first) {
+                    first = false;
+                    u32 t = touched | row_ror32<8>(touched);
+                    t |= row_ror32<4>(t);
+                    t |= row_ror32<2>(t);
+                    t |= row_ror32<1>(t);
+                    tile_windows = __builtin_amdgcn_readlane(t, 0) | __builtin_amdgcn_readlane(t, 16) | __builtin_amdgcn_readlane(t, 32) | __builtin_amdgcn_readlane(t, 48);
+                    if (RK_ABLATE & 4096) tile_windows = 0xFFFFu;
+                    load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
+                    RK_STAMP(1);  // probe + emit
+                    if (overflow) {  // the whole tree does not fit: start over, in halves (part becomes 0 again)
+                        split = true;
+                        part = ~0u;
+                        continue;
+                    }
+                }
+                for (u32 w = wa; w < wb; w++) {
+                    if (!((tile_windows >> w) & 1u)) continue;
+                    window_accumulate(w);
+                    const u32 wlo = w * W;
+                    const u32 win_n = nb - wlo < W ? nb - wlo : W;
+                    if (phase == 0) {
+                        heads_scan_reset<G>(S, win_n, li, wlo, hd);
+                        wave_lds_fence();
+                        RK_STAMP(4);  // window scan + reset
+                        continue;
+                    }
+                    // ---- exact select over the window, merged into the K best so far ----
+                    u64 win_key = 0;
+                    if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key RK_STAMP_ARGS);  // (timing only)
+                    wave_lds_fence();
+                    if (win_key != 0ull) win_key -= (u64)wlo;  // window-relative branch -> tree id (low 16 bits hold 0xFFFF - branch)
+                    const u64 moved = ((u64)row_ror32<8>((u32)(win_key >> 32)) << 32) | row_ror32<8>((u32)win_key);  // lane r -> lane r + 8
+                    const u64 comb = li < 8 ? acc_key : moved;
+                    const int rank = RankAbove<G, G - 1>::run(comb, li);
+                    work64[li] = 0ull;
+                    wave_lds_fence();
+                    if (comb != 0ull && rank < K) work64[rank] = comb;
+                    wave_lds_fence();
+                    acc_key = (int)li < K ? work64[li] : 0ull;
+                    wave_lds_fence();
+                }
+            }
+            if (phase == 0) {
+                heads_rounds<G>(hd, K, li, gi, acc_key, doubt);
+                RK_STAMP(5);  // rounds
             }
         }
         const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);

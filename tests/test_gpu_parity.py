@@ -670,6 +670,26 @@ def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window()
     assert st["placed"] == 1200
 
 
+@pytest.mark.parametrize("n_branches,mean_row", [(7999, 26), (3999, 30), (15999, 18)])
+def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, mean_row):
+    """every k-mer hits a row of two units on average: ~300 row units per 150-bp read, more than the main list holds for the whole
+    tree but not for half of its windows -> the tile is emitted once per half; mixed with short reads (fit whole) and 250-bp reads
+    (do not fit a half either: the per-window probe)"""
+    sdb = synth.make_db(4, 7, n_branches, 16384, 16384 * mean_row, seed=n_branches)
+    odb = O.OracleDB.from_synth(sdb)
+    parts = [synth.make_reads(4, 900, 150, seed=21), synth.make_reads(4, 300, 60, seed=22, var_len=30), synth.make_reads(4, 150, 250, seed=23)]
+    seq = np.concatenate([p[0] for p in parts])
+    lens = np.concatenate([(p[1][1:] - p[1][:-1]) for p in parts])
+    order = np.random.default_rng(3).permutation(len(lens))  # tiles of mixed shapes
+    starts = np.concatenate([[0], np.cumsum(lens)])[:-1]
+    seq2 = np.concatenate([seq[int(starts[i]):int(starts[i] + lens[i])] for i in order])
+    off2 = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off2[1:] = np.cumsum(lens[order])
+    for K in (7, 3):
+        _, _, st = run_case(sdb, odb, seq2, off2, "direct", 0, "mean", keepAtMost=K)
+        assert st["placed"] == len(lens)
+
+
 def test_windowed_kernel_protein_and_keep_at_most():
     sdb = synth.make_db(20, 3, 3100, 6000, 60000, seed=6)
     odb = O.OracleDB.from_synth(sdb)
