@@ -13,7 +13,9 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <new>
 #include <string>
 #include <thread>
@@ -78,7 +80,21 @@ extern "C" const char *rk_last_error(void) { return g_err; }
 template <typename K>
 static int resident_blocks(K kern, int block_threads, size_t lds, uint64_t by_lds, uint64_t &out) {
     int n = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, block_threads, lds));
+    {  // (asked once per kernel, block size, LDS size and device: the query is not free next to a small launch)
+        static std::mutex mu;
+        static std::map<std::tuple<const void *, int, size_t, int>, int> known;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        const auto key = std::make_tuple((const void *)kern, block_threads, lds, dev);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = known.find(key);
+        if (it != known.end()) {
+            n = it->second;
+        } else {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, block_threads, lds));
+            known.emplace(key, n);
+        }
+    }
     if (n < 1) return fail(RK_ERR_UNSUPPORTED, "internal: kernel does not fit a CU (%d threads, %zu B of LDS per block)", block_threads, lds);
     out = by_lds < (uint64_t)n ? by_lds : (uint64_t)n;
     static const bool trace = getenv("RK_TRACE_GRID") != nullptr;  // developer knob
