@@ -4,6 +4,7 @@ Bar: flags / n_rows / branches identical, scores bit-equal (float32), LWR within
 Reads whose top-(K+1) hold an exact float tie are compared as described in tests/util.py (the reference's order
 among equal scores depends on its hash-map layout)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -23,6 +24,9 @@ MODES = {"direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": r
 def c2_small():
     sdb = synth.make_config_db("C2", scale=0.2)
     return sdb, O.OracleDB.from_synth(sdb)
+
+
+_EXTRA_SEEDS = int(os.environ.get("RK_TEST_EXTRA_SEEDS", "0"))  # soak runs: more seeds for the randomised sweeps
 
 
 def run_case(sdb, odb, seq, off, table="direct", lanes=0, amb="mean", **kw):
@@ -336,7 +340,7 @@ def test_place_batch_multi_equals_single_call(c2_small):
             d.close()
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 + _EXTRA_SEEDS))
 def test_randomised_configurations(seed):
     """Differential sweep: random alphabet / k / tree size / row lengths / read lengths / parameters / table flavour / lane-group
     width, engine against oracle (small sizes, seeded)."""
@@ -778,7 +782,7 @@ def test_long_protein_kmers_mid_size_and_large_trees():
         run_case(sdb, odb, seq, off, "hash", 0, "mean")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + _EXTRA_SEEDS))
 def test_randomised_long_kmers_and_tree_sizes(seed):
     """Differential sweep over the corners the small sweep cannot reach: hashed k-mer spaces (DNA k 13..31, amino acids k 5..12),
     trees from a few branches to the reference's 65 534, mid-size (windowed) and large (indexed, multi-pass) images."""
