@@ -67,7 +67,7 @@ def build_engine(force=False, verbose=False):
 
 
 HOST_BIN = os.path.join(ROOT, "rappas_amd", "bin", "rk_place")
-HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("rk_place_main.cpp", "rk_hostio.hpp")]
+HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("rk_place_main.cpp", "rk_hostio.hpp", "rk_javaser.hpp")]
 
 
 def build_host_tools(force=False, verbose=False):

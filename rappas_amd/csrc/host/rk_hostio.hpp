@@ -5,6 +5,7 @@
 // reference root):
 //   N3  FASTA ingest  src/inputs/FASTAPointer.java:66-149 ; dedup src/core/algos/PlacementProcess.java:591-629 (MD5, Jacksum)
 //   N2  --jsondb      src/main_v2/SessionNext_v2.java:214-270 (json-simple dump with two bare toString() tokens)
+//       --uniondb     src/main_v2/SessionNext_v2.java:109-207 (Java serialization stream, read by rk_javaser.hpp)
 //   N1  jplace        src/main_v2/Main_PLACEMENT_v07.java:224-315, src/core/algos/PlacementProcess.java:1005-1046,
 //                     src/tree/NewickReader.java:46-160, src/tree/PhyloTree.java:408-439, src/tree/NewickWriter.java:116-212
 // rappas_amd/hostio.py is the same logic in Python; tests/test_host_cpp.py requires byte-identical output from the two.
@@ -22,6 +23,8 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include "rk_javaser.hpp"
 
 namespace rkh {
 
@@ -636,6 +639,142 @@ inline JsonDb load_jsondb(const std::string &text) {
     if (!db.k || !have_hash || db.original_tree.empty()) throw std::runtime_error("jsondb: k, originalTree or hash missing");
     for (uint64_t c : db.key_codes)
         if (db.k < 32 && (c >> (2 * db.k))) throw std::runtime_error("jsondb: k-mer longer than k");
+    return db;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// N2: a `.union` database (SessionNext_v2.storeHash, src/main_v2/SessionNext_v2.java:109-147; read back by load, :158-207): a
+// Java serialization stream holding, in this order, block data {int k, int minK, float omega, int branchPerEdge, float
+// stateThreshold, float PPStarThreshold, float PPStarThresholdAsLog10}, the objects states, align, originalTree, extendedTree,
+// ARTree, nodeMapping, block data {float calibrationNormScore, boolean onlyFakes} and the CustomHash_v4_FastUtil81.  Taken from
+// the object graph (the same as rappas_amd/hostio.py: load_uniondb):
+//   * alphabet: the class of `states` (core.DNAStatesShifted / core.AAStates; --convertUO shows as 'U' in AAStates' char map);
+//   * tree: PhyloTree.indexById (HashMap<Integer, PhyloNode>, src/tree/PhyloTree.java:39) -> per node id, label, branch length,
+//     jplace edge id (src/tree/PhyloNode.java:30-37) and, from its DefaultMutableTreeNode part, parent and ordered children;
+//   * rows: CustomHash_v4_FastUtil81.hash, an Object2ObjectOpenCustomHashMap<byte[], Char2FloatOpenHashMap>
+//     (src/core/hash/CustomHash_v4_FastUtil81.java:36): fastutil writes its open-hash maps as defaultWriteObject() followed by
+//     the entries -- writeObject(key), writeObject(value) for the outer map, writeChar(key), writeFloat(value) for a row.  DNA
+//     keys are compressMer bytes (DNAStatesShifted.java:115-143: little-endian 2-bit codes), AA keys one state per byte.
+// PARITY UNPINNED (rk_javaser.hpp): never run against a file written by a JVM.
+// ------------------------------------------------------------------------------------------------------------------
+struct UnionDb {
+    uint32_t alphabet = 0, k = 0;
+    bool convert_uo = false, only_fakes = false;
+    float thr = 0, thr_log10 = 0, omega = 0, calibration = 0;
+    Tree tree;
+    std::vector<uint64_t> key_codes, row_offsets{0};
+    std::vector<uint16_t> branch_ids;
+    std::vector<float> scores;
+};
+
+inline UnionDb load_uniondb(const std::string &data) {
+    using rkjs::Node;
+    using rkjs::P;
+    auto be32 = [](const char *b) { return (uint32_t)(uint8_t)b[0] << 24 | (uint32_t)(uint8_t)b[1] << 16 | (uint32_t)(uint8_t)b[2] << 8 | (uint32_t)(uint8_t)b[3]; };
+    auto bef = [&](const char *b) { const uint32_t u = be32(b); float x; memcpy(&x, &u, 4); return x; };
+    const std::vector<rkjs::Record> recs = rkjs::parse(data);
+    std::string blocks;
+    std::vector<P> objs;
+    for (const auto &r : recs) {
+        if (r.is_block) blocks += r.value->s;
+        else objs.push_back(r.value);
+    }
+    if (blocks.size() < 33 || objs.size() < 7)
+        throw std::runtime_error("union: expected 33 bytes of scalars and 7 objects, found " + std::to_string(blocks.size()) + " and " +
+                                 std::to_string(objs.size()) + " (a database stored without its hash?)");
+    UnionDb db;
+    db.k = be32(&blocks[0]);
+    db.omega = bef(&blocks[8]);
+    db.thr = bef(&blocks[20]);
+    db.thr_log10 = bef(&blocks[24]);
+    db.calibration = bef(&blocks[28]);
+    db.only_fakes = blocks[32] != 0;
+    const P states = objs[0], otree = objs[2], chash = objs[6];
+    if (!states || states->kind != Node::OBJECT || !otree || otree->kind != Node::OBJECT || !chash || chash->kind != Node::OBJECT)
+        throw std::runtime_error("union: states, originalTree or the hash is not an object");
+    if (states->classname() == "core.DNAStatesShifted") {
+        db.alphabet = 4;
+    } else if (states->classname() == "core.AAStates") {
+        db.alphabet = 20;
+        if (const P b = states->get("b"))
+            for (const auto &kv : rkjs::hashmap_items(*b))
+                if (kv.first && rkjs::boxed_int(kv.first) == 'U') db.convert_uo = true;
+    } else {
+        throw std::runtime_error("union: unknown States class " + states->classname());
+    }
+    // ---- original tree ----
+    const P index = otree->get("indexById");
+    if (!index) throw std::runtime_error("union: originalTree has no indexById map");
+    const auto items = rkjs::hashmap_items(*index);
+    const size_t n_nodes = items.size();
+    db.tree.nodes.assign(n_nodes, rkh::Node());
+    std::map<const Node *, int> ident;
+    std::vector<P> jn(n_nodes);
+    std::vector<bool> seen(n_nodes, false);
+    for (const auto &kv : items) {
+        const int64_t id = rkjs::boxed_int(kv.first);
+        if (id < 0 || (size_t)id >= n_nodes) throw std::runtime_error("union: node id " + std::to_string(id) + " outside 0.." + std::to_string(n_nodes - 1));
+        if (!kv.second || kv.second->kind != Node::OBJECT || seen[(size_t)id]) throw std::runtime_error("union: indexById holds node " + std::to_string(id) + " twice or as null");
+        seen[(size_t)id] = true;
+        jn[(size_t)id] = kv.second;
+        ident[kv.second.get()] = (int)id;
+        rkh::Node &n = db.tree.nodes[(size_t)id];
+        n.id = (int)id;
+        const P label = kv.second->get("label"), bl = kv.second->get("branchLengthToAncestor"), je = kv.second->get("jplaceEdgeId");
+        n.label = label && label->kind == Node::STRING ? label->s : std::string();
+        if (!bl || !je) throw std::runtime_error("union: PhyloNode without branchLengthToAncestor / jplaceEdgeId");
+        n.bl = (float)bl->f;
+        n.jplace_edge = (int)je->i;
+    }
+    for (size_t id = 0; id < n_nodes; id++) {
+        const P ch = jn[id]->get("children");
+        if (!ch) continue;
+        for (const P &c : rkjs::list_items(*ch)) {
+            auto it = ident.find(c.get());
+            if (it == ident.end()) throw std::runtime_error("union: a child of node " + std::to_string(id) + " is not in indexById");
+            db.tree.nodes[id].children.push_back(it->second);
+            db.tree.nodes[(size_t)it->second].parent = (int)id;
+        }
+    }
+    db.tree.root = -1;
+    for (size_t id = 0; id < n_nodes; id++)
+        if (db.tree.nodes[id].parent < 0 && db.tree.root < 0) db.tree.root = (int)id;
+    if (db.tree.root < 0) throw std::runtime_error("union: the tree has no root");
+    // ---- hash ----
+    const P outer = chash->get("hash");
+    if (!outer || outer->kind != Node::OBJECT) throw std::runtime_error("union: CustomHash_v4_FastUtil81 without its map");
+    const std::string oname = "it.unimi.dsi.fastutil.objects.Object2ObjectOpenCustomHashMap", rname = "it.unimi.dsi.fastutil.chars.Char2FloatOpenHashMap";
+    const std::vector<P> kv = outer->objects(oname);
+    const P osize = outer->get("size");
+    const int64_t n_keys = osize ? osize->i : -1;
+    if (n_keys < 0 || kv.size() != (size_t)(2 * n_keys))
+        throw std::runtime_error("union: outer map announces " + std::to_string(n_keys) + " entries, stream holds " + std::to_string(kv.size() / 2));
+    for (int64_t r = 0; r < n_keys; r++) {
+        const P key = kv[(size_t)(2 * r)], row = kv[(size_t)(2 * r + 1)];
+        if (!key || key->kind != Node::ARRAY || !row || row->kind != Node::OBJECT) throw std::runtime_error("union: malformed entry of the outer map");
+        const std::string &raw = key->s;
+        uint64_t code = 0;
+        if (db.alphabet == 4) {
+            if (raw.size() > 8) throw std::runtime_error("union: DNA key longer than 8 bytes");
+            for (size_t b = 0; b < raw.size(); b++) code |= (uint64_t)(uint8_t)raw[b] << (8 * b);  // compressMer bytes: base i at bits 2*(i%4) of byte i/4
+            if (db.k < 32 && (code >> (2 * db.k))) throw std::runtime_error("union: DNA key has bits beyond 2k");
+        } else {
+            if (raw.size() > 12) throw std::runtime_error("union: amino-acid key longer than 12 states");
+            for (size_t b = 0; b < raw.size(); b++) code |= (uint64_t)(uint8_t)raw[b] << (5 * b);
+        }
+        db.key_codes.push_back(code);
+        const P rsize = row->get("size");
+        const int64_t m = rsize ? rsize->i : -1;
+        const std::string blob = row->block(rname);
+        if (m < 0 || blob.size() != (size_t)(6 * m))
+            throw std::runtime_error("union: row announces " + std::to_string(m) + " entries, stream holds " + std::to_string(blob.size()) + " bytes");
+        for (int64_t e = 0; e < m; e++) {
+            const char *b = &blob[(size_t)(6 * e)];
+            db.branch_ids.push_back((uint16_t)((uint8_t)b[0] << 8 | (uint8_t)b[1]));
+            db.scores.push_back(bef(b + 2));
+        }
+        db.row_offsets.push_back(db.branch_ids.size());
+    }
     return db;
 }
 

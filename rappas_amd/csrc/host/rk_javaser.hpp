@@ -1,0 +1,354 @@
+// rk_javaser.hpp -- a reader for the Java Object Serialization Stream Protocol (what ObjectOutputStream writes), just enough of
+// it to open a RAPPAS `.union` database without a JVM (src/main_v2/SessionNext_v2.java:109-207).  C++ twin of
+// rappas_amd/javaser.py; the two are compared with each other in tests/test_host_cpp.py.
+//
+// Generic by construction: the stream describes every class it contains (name, serialVersionUID, flags, field list, super
+// class), so objects of classes this file has never heard of -- the Swing JTree machinery tree.PhyloTree drags in, fastutil's
+// maps -- are parsed from their own descriptors: default field data class by class (super class first), then, for classes with
+// a writeObject method (SC_WRITE_METHOD), the "annotation" records up to TC_ENDBLOCKDATA.  Nothing is instantiated.  Grammar:
+// Java Object Serialization Specification, chapter 6; handles are assigned in the order the specification gives (newHandle).
+//
+// HOST-SIDE INGEST ONLY; nothing here touches the placement path.  PARITY UNPINNED: no JVM exists
+// in this environment, so this reader has only ever seen streams assembled by tests/javaser_writer.py from the same
+// specification, never a file a JVM wrote.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace rkjs {
+
+enum : uint8_t {
+    TC_NULL = 0x70, TC_REFERENCE, TC_CLASSDESC, TC_OBJECT, TC_STRING, TC_ARRAY, TC_CLASS, TC_BLOCKDATA, TC_ENDBLOCKDATA, TC_RESET,
+    TC_BLOCKDATALONG, TC_EXCEPTION, TC_LONGSTRING, TC_PROXYCLASSDESC, TC_ENUM
+};
+enum : uint8_t { SC_WRITE_METHOD = 0x01, SC_SERIALIZABLE = 0x02, SC_EXTERNALIZABLE = 0x04, SC_BLOCK_DATA = 0x08 };
+constexpr int32_t BASE_WIRE_HANDLE = 0x7E0000;
+
+struct Error : std::runtime_error {
+    Error(const std::string &msg, size_t offset) : std::runtime_error(msg + " (stream offset " + std::to_string(offset) + ")") {}
+};
+
+struct ClassDesc {
+    std::string name;
+    int64_t uid = 0;
+    uint8_t flags = 0;
+    struct Field { char type; std::string name; };
+    std::vector<Field> fields;
+    std::shared_ptr<ClassDesc> super;
+    std::vector<const ClassDesc *> hierarchy() const {  // super class first, as class data is laid out in the stream
+        std::vector<const ClassDesc *> chain;
+        for (const ClassDesc *d = this; d; d = d->super.get()) chain.insert(chain.begin(), d);
+        return chain;
+    }
+};
+
+struct Node;
+using P = std::shared_ptr<Node>;  // nullptr = Java null
+
+struct Node {
+    enum Kind { PRIM, STRING, OBJECT, ARRAY, CLASSDESC, ENUM, BLOCK } kind;
+    char ptype = 0;  // PRIM: B C D F I J S Z
+    int64_t i = 0;   // PRIM integral value (C as its UTF-16 code unit, Z as 0/1)
+    double f = 0;    // PRIM D / F
+    std::string s;   // STRING text, BLOCK bytes, byte[] contents, ENUM constant name
+    std::shared_ptr<ClassDesc> desc;
+    std::vector<std::pair<std::string, std::map<std::string, P>>> fields;  // OBJECT: class name -> {field name: value}
+    std::vector<std::pair<std::string, std::vector<P>>> annotations;       // OBJECT: class name -> what its writeObject wrote after the fields
+    std::vector<P> elems;                                                  // ARRAY (byte[] keeps its bytes in s instead)
+    explicit Node(Kind k) : kind(k) {}
+
+    const std::string &classname() const { return desc->name; }
+    // value of `field` looked up from the most derived class upwards; found = false when no class has it
+    P get(const std::string &field, bool *found = nullptr) const {
+        for (size_t c = fields.size(); c-- > 0;) {
+            auto it = fields[c].second.find(field);
+            if (it != fields[c].second.end()) {
+                if (found) *found = true;
+                return it->second;
+            }
+        }
+        if (found) *found = false;
+        return nullptr;
+    }
+    const std::vector<P> *annotation(const std::string &cls) const {
+        for (const auto &a : annotations)
+            if (a.first == cls) return &a.second;
+        return nullptr;
+    }
+    std::string block(const std::string &cls) const {  // the block-data bytes of one class's annotations, concatenated
+        std::string out;
+        if (const auto *a = annotation(cls))
+            for (const P &x : *a)
+                if (x && x->kind == BLOCK) out += x->s;
+        return out;
+    }
+    std::vector<P> objects(const std::string &cls) const {  // the same annotations without the block data (nulls kept)
+        std::vector<P> out;
+        if (const auto *a = annotation(cls))
+            for (const P &x : *a)
+                if (!x || x->kind != BLOCK) out.push_back(x);
+        return out;
+    }
+};
+
+struct Record {
+    bool is_block;
+    P value;  // BLOCK node, or the object (nullptr for a null written with writeObject)
+};
+
+class Reader {
+  public:
+    Reader(const uint8_t *data, size_t n) : d_(data), n_(n) {
+        if (u2() != 0xACED || u2() != 5) throw Error("not a Java serialization stream (bad magic / version)", 0);
+    }
+    // top-level records: block data for primitive writes, objects for writeObject calls
+    std::vector<Record> contents() {
+        std::vector<Record> out;
+        while (p_ < n_) {
+            const uint8_t tc = d_[p_];
+            if (tc == TC_BLOCKDATA || tc == TC_BLOCKDATALONG) out.push_back({true, blockdata()});
+            else if (tc == TC_RESET) { p_++; handles_.clear(); }
+            else out.push_back({false, content()});
+        }
+        return out;
+    }
+
+  private:
+    const uint8_t *d_;
+    size_t n_, p_ = 0;
+    struct Handle { P node; std::shared_ptr<ClassDesc> desc; };
+    std::vector<Handle> handles_;
+
+    const uint8_t *take(size_t n) {
+        if (n > n_ - p_) throw Error("truncated stream", p_);
+        const uint8_t *b = d_ + p_;
+        p_ += n;
+        return b;
+    }
+    uint8_t u1() { return *take(1); }
+    uint16_t u2() { const uint8_t *b = take(2); return (uint16_t)(b[0] << 8 | b[1]); }
+    int32_t i4() { const uint8_t *b = take(4); return (int32_t)((uint32_t)b[0] << 24 | (uint32_t)b[1] << 16 | (uint32_t)b[2] << 8 | b[3]); }
+    int64_t i8() { const uint64_t hi = (uint32_t)i4(), lo = (uint32_t)i4(); return (int64_t)(hi << 32 | lo); }
+    std::string utf(bool lng = false) {
+        const int64_t n = lng ? i8() : u2();
+        if (n < 0) throw Error("negative string length", p_);
+        const uint8_t *b = take((size_t)n);
+        return std::string((const char *)b, (size_t)n);  // modified UTF-8 kept as is (names and labels here are ASCII)
+    }
+    size_t new_handle(P node, std::shared_ptr<ClassDesc> desc = nullptr) {
+        handles_.push_back({std::move(node), std::move(desc)});
+        return handles_.size() - 1;
+    }
+    P blockdata() {
+        const uint8_t tc = u1();
+        const int64_t n = tc == TC_BLOCKDATA ? u1() : i4();
+        if (n < 0) throw Error("negative block length", p_);
+        auto b = std::make_shared<Node>(Node::BLOCK);
+        const uint8_t *raw = take((size_t)n);
+        b->s.assign((const char *)raw, (size_t)n);
+        return b;
+    }
+    P prim(char t) {
+        auto v = std::make_shared<Node>(Node::PRIM);
+        v->ptype = t;
+        switch (t) {
+        case 'B': v->i = (int8_t)u1(); break;
+        case 'Z': v->i = u1() != 0; break;
+        case 'C': v->i = u2(); break;
+        case 'S': v->i = (int16_t)u2(); break;
+        case 'I': v->i = i4(); break;
+        case 'J': v->i = i8(); break;
+        case 'F': { const uint32_t b = (uint32_t)i4(); float x; memcpy(&x, &b, 4); v->f = x; break; }
+        case 'D': { const uint64_t b = (uint64_t)i8(); double x; memcpy(&x, &b, 8); v->f = x; break; }
+        default: throw Error(std::string("unknown primitive type code '") + t + "'", p_);
+        }
+        return v;
+    }
+    static bool is_prim(char t) { return strchr("BCDFIJSZ", t) != nullptr && t != 0; }
+
+    // one `object` production
+    P content() {
+        const size_t at = p_;
+        const uint8_t tc = u1();
+        switch (tc) {
+        case TC_NULL: return nullptr;
+        case TC_REFERENCE: {
+            const int64_t h = (int64_t)i4() - BASE_WIRE_HANDLE;
+            if (h < 0 || h >= (int64_t)handles_.size()) throw Error("back reference to unknown handle " + std::to_string(h), at);
+            const Handle &hd = handles_[(size_t)h];
+            if (hd.desc) {  // a class descriptor used as a value
+                auto c = std::make_shared<Node>(Node::CLASSDESC);
+                c->desc = hd.desc;
+                return c;
+            }
+            return hd.node;
+        }
+        case TC_STRING: case TC_LONGSTRING: {
+            auto s = std::make_shared<Node>(Node::STRING);
+            new_handle(s);
+            s->s = utf(tc == TC_LONGSTRING);
+            return s;
+        }
+        case TC_CLASSDESC: case TC_PROXYCLASSDESC: {
+            p_ = at;
+            auto c = std::make_shared<Node>(Node::CLASSDESC);
+            c->desc = classdesc();
+            return c;
+        }
+        case TC_CLASS: {
+            auto c = std::make_shared<Node>(Node::CLASSDESC);
+            c->desc = classdesc();
+            new_handle(c);
+            return c;
+        }
+        case TC_ENUM: {
+            auto e = std::make_shared<Node>(Node::ENUM);
+            e->desc = classdesc();
+            new_handle(e);
+            const P name = content();
+            if (name && name->kind == Node::STRING) e->s = name->s;
+            return e;
+        }
+        case TC_ARRAY: {
+            auto a = std::make_shared<Node>(Node::ARRAY);
+            a->desc = classdesc();
+            if (!a->desc) throw Error("array without a class descriptor", at);
+            new_handle(a);
+            const int32_t n = i4();
+            if (n < 0) throw Error("negative array length", at);
+            const char t = a->desc->name.size() > 1 ? a->desc->name[1] : '?';
+            if (t == 'B') {
+                const uint8_t *raw = take((size_t)n);
+                a->s.assign((const char *)raw, (size_t)n);  // byte[]: kept as bytes (k-mer keys)
+            } else if (is_prim(t)) {
+                a->elems.reserve((size_t)n);
+                for (int32_t e = 0; e < n; e++) a->elems.push_back(prim(t));
+            } else {
+                for (int32_t e = 0; e < n; e++) a->elems.push_back(content());
+            }
+            return a;
+        }
+        case TC_OBJECT: {
+            auto o = std::make_shared<Node>(Node::OBJECT);
+            o->desc = classdesc();
+            if (!o->desc) throw Error("object without a class descriptor", at);
+            new_handle(o);
+            classdata(*o);
+            return o;
+        }
+        case TC_EXCEPTION: throw Error("the stream records an exception thrown while it was written", at);
+        case TC_BLOCKDATA: case TC_BLOCKDATALONG: case TC_ENDBLOCKDATA:
+            throw Error("block data record where an object is expected", at);
+        default: throw Error("unknown type code " + std::to_string(tc), at);
+        }
+    }
+
+    std::shared_ptr<ClassDesc> classdesc() {
+        const size_t at = p_;
+        const uint8_t tc = u1();
+        if (tc == TC_NULL) return nullptr;
+        if (tc == TC_REFERENCE) {
+            const int64_t h = (int64_t)i4() - BASE_WIRE_HANDLE;
+            if (h < 0 || h >= (int64_t)handles_.size() || !handles_[(size_t)h].desc)
+                throw Error("class descriptor reference does not name a class descriptor", at);
+            return handles_[(size_t)h].desc;
+        }
+        if (tc == TC_PROXYCLASSDESC) {
+            auto d = std::make_shared<ClassDesc>();
+            d->name = "<proxy>";
+            d->flags = SC_SERIALIZABLE;
+            new_handle(nullptr, d);
+            const int32_t n = i4();
+            for (int32_t e = 0; e < n; e++) utf();
+            annotations();
+            d->super = classdesc();
+            return d;
+        }
+        if (tc != TC_CLASSDESC) throw Error("type code " + std::to_string(tc) + " where a class descriptor is expected", at);
+        auto d = std::make_shared<ClassDesc>();
+        d->name = utf();
+        d->uid = i8();
+        new_handle(nullptr, d);
+        d->flags = u1();
+        const uint16_t nf = u2();
+        for (uint16_t e = 0; e < nf; e++) {
+            const char t = (char)u1();
+            std::string fname = utf();
+            if (t == '[' || t == 'L') content();  // class name of an object / array field: a String object
+            d->fields.push_back({t, std::move(fname)});
+        }
+        annotations();  // classAnnotation (annotateClass writes nothing by default)
+        d->super = classdesc();
+        return d;
+    }
+
+    std::vector<P> annotations() {
+        std::vector<P> out;
+        while (true) {
+            if (p_ >= n_) throw Error("truncated stream inside an annotation", p_);
+            const uint8_t tc = d_[p_];
+            if (tc == TC_ENDBLOCKDATA) { p_++; return out; }
+            if (tc == TC_BLOCKDATA || tc == TC_BLOCKDATALONG) out.push_back(blockdata());
+            else if (tc == TC_RESET) p_++;
+            else out.push_back(content());
+        }
+    }
+
+    void classdata(Node &obj) {
+        for (const ClassDesc *d : obj.desc->hierarchy()) {
+            if (d->flags & SC_SERIALIZABLE) {
+                std::map<std::string, P> vals;
+                for (const auto &f : d->fields) vals[f.name] = is_prim(f.type) ? prim(f.type) : content();
+                obj.fields.emplace_back(d->name, std::move(vals));
+                if (d->flags & SC_WRITE_METHOD) obj.annotations.emplace_back(d->name, annotations());
+            } else if (d->flags & SC_EXTERNALIZABLE) {
+                if (!(d->flags & SC_BLOCK_DATA)) throw Error(d->name + ": Externalizable data of stream protocol 1 cannot be delimited", p_);
+                obj.annotations.emplace_back(d->name, annotations());
+            } else {
+                throw Error(d->name + ": class descriptor is neither Serializable nor Externalizable", p_);
+            }
+        }
+    }
+};
+
+inline std::vector<Record> parse(const std::string &data) { return Reader((const uint8_t *)data.data(), data.size()).contents(); }
+
+// ---- java.util containers by their documented serial forms ----
+// java.util.HashMap / LinkedHashMap: writeObject = defaultWriteObject, then block data {int buckets, int size}, then key, value
+// objects alternately (java.util.HashMap.writeObject / internalWriteEntries)
+inline std::vector<std::pair<P, P>> hashmap_items(const Node &obj) {
+    const std::vector<P> objs = obj.objects("java.util.HashMap");
+    std::vector<std::pair<P, P>> out;
+    for (size_t e = 0; e + 1 < objs.size(); e += 2) out.emplace_back(objs[e], objs[e + 1]);
+    return out;
+}
+// java.lang.Integer / Character ... -> the integral value (field `value` of the wrapper class)
+inline int64_t boxed_int(const P &v) {
+    if (!v) throw std::runtime_error("union: null where a boxed number is expected");
+    if (v->kind == Node::PRIM) return v->i;
+    const P x = v->get("value");
+    if (!x || x->kind != Node::PRIM) throw std::runtime_error("union: " + (v->desc ? v->desc->name : std::string("value")) + " is not a boxed number");
+    return x->i;
+}
+// java.util.ArrayList: defaultWriteObject (size), block data {int capacity}, then the elements; java.util.Vector: default fields
+// (elementData array, elementCount)
+inline std::vector<P> list_items(const Node &obj) {
+    bool is_vector = obj.classname() == "java.util.Vector";
+    for (const auto &f : obj.fields) is_vector = is_vector || f.first == "java.util.Vector";
+    if (is_vector) {
+        const P n = obj.get("elementCount"), data = obj.get("elementData");
+        std::vector<P> out;
+        if (data)
+            for (size_t e = 0; e < data->elems.size() && (int64_t)e < (n ? n->i : 0); e++) out.push_back(data->elems[e]);
+        return out;
+    }
+    return obj.objects("java.util.ArrayList");
+}
+
+}  // namespace rkjs

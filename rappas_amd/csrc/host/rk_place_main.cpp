@@ -1,4 +1,5 @@
-// rk_place -- FASTA queries + a `--jsondb` database dump -> .jplace through librappas_place.so, no JVM and no Python.
+// rk_place -- FASTA queries + a `--jsondb` database dump or the reference's own `.union` file -> .jplace through
+// librappas_place.so, no JVM and no Python.
 // The reference's `-p p` phase for one query file (src/main_v2/Main_PLACEMENT_v07.java:150-320): ingest and the jplace writer
 // are rk_hostio.hpp, the placement itself is rk_place_batch (GPU; there is no CPU fallback).
 // Same options and byte-identical output as `python -m rappas_amd.tools.place`.
@@ -20,7 +21,7 @@ static std::string slurp(const std::string &path) {
 }
 
 static int usage() {
-    std::cerr << "usage: rk_place --jsondb DB.json --fasta READS.fa --out OUT.jplace [--keep-at-most 7] [--keep-factor 0.01]\n"
+    std::cerr << "usage: rk_place (--jsondb DB.json | --uniondb DB.union) --fasta READS.fa --out OUT.jplace [--keep-at-most 7] [--keep-factor 0.01]\n"
                  "                [--amb mean|max|skip] [--nsbound X] [--guppy-compat] [--device 0] [--logs DIR]\n"
                  "       rk_place --emit-tree TREE.nwk | --format-float X | --format-double X | --dedup READS.fa | --md5 TEXT\n";
     return 2;
@@ -28,7 +29,7 @@ static int usage() {
 
 int main(int argc, char **argv) {
     try {
-        std::string jsondb, fasta, out, amb = "mean", logs;
+        std::string jsondb, uniondb, fasta, out, amb = "mean", logs;
         bool logs_given = false;
         uint32_t keep_at_most = 7;
         float keep_factor = 0.01f, nsbound = -INFINITY;
@@ -40,6 +41,7 @@ int main(int argc, char **argv) {
             const std::string a = argv[i];
             auto val = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error("missing value after " + a); return argv[++i]; };
             if (a == "--jsondb") jsondb = val();
+            else if (a == "--uniondb") uniondb = val();
             else if (a == "--fasta") fasta = val();
             else if (a == "--out") out = val();
             else if (a == "--keep-at-most") keep_at_most = (uint32_t)std::stoul(val());
@@ -84,6 +86,20 @@ int main(int argc, char **argv) {
                           << "parse " << recs.size() / (t1 - t0) / 1e6 << " Mreads/s (" << text.size() / (t1 - t0) / 1e6 << " MB/s)\n"
                           << "dedup " << recs.size() / (t2 - t1) / 1e6 << " Mreads/s\n";
                 return 0;
+            } else if (a == "--load-uniondb") {  // what load_uniondb makes of a `.union` stream (compared with the Python twin)
+                const rkh::UnionDb db = rkh::load_uniondb(slurp(val()));
+                std::cout << db.alphabet << " " << db.k << " " << (db.convert_uo ? 1 : 0) << " " << (db.only_fakes ? 1 : 0) << " "
+                          << rkh::java_float_to_string(db.thr) << " " << rkh::java_float_to_string(db.thr_log10) << " "
+                          << rkh::java_float_to_string(db.omega) << " " << rkh::java_float_to_string(db.calibration) << " "
+                          << db.key_codes.size() << " " << db.scores.size() << "\n" << rkh::jplace_newick(db.tree) << "\n";
+                for (const auto &n : db.tree.nodes) std::cout << n.id << "\t" << n.label << "\t" << n.jplace_edge << "\t" << n.parent << "\n";
+                for (size_t r = 0; r < db.key_codes.size(); r++) {
+                    std::cout << db.key_codes[r];
+                    for (uint64_t e = db.row_offsets[r]; e < db.row_offsets[r + 1]; e++)
+                        std::cout << " " << db.branch_ids[e] << ":" << rkh::java_float_to_string(db.scores[e]);
+                    std::cout << "\n";
+                }
+                return 0;
             } else if (a == "--load-jsondb") {
                 const rkh::JsonDb db = rkh::load_jsondb(slurp(val()));
                 std::cout << db.k << " " << rkh::java_float_to_string(db.thr) << " " << rkh::java_float_to_string(db.thr_log10) << " "
@@ -97,18 +113,30 @@ int main(int argc, char **argv) {
                 return 0;
             } else return usage();
         }
-        if (jsondb.empty() || fasta.empty() || out.empty()) return usage();
+        if ((jsondb.empty() == uniondb.empty()) || fasta.empty() || out.empty()) return usage();
         uint32_t amb_mode;
         if (amb == "mean") amb_mode = RK_AMB_MEAN; else if (amb == "max") amb_mode = RK_AMB_MAX; else if (amb == "skip") amb_mode = RK_AMB_SKIP;
         else return usage();
 
-        const rkh::JsonDb jd = rkh::load_jsondb(slurp(jsondb));
-        const rkh::Tree tree = rkh::parse_newick(jd.original_tree);
+        rkh::JsonDb jd;
+        rkh::UnionDb ud;
+        rkh::Tree tree;
         rk_db_desc d;
         memset(&d, 0, sizeof(d));
-        d.alphabet = RK_ALPHABET_DNA; d.k = jd.k; d.n_branches = (uint32_t)tree.nodes.size();
-        d.thr_log10 = jd.thr_log10; d.thr = jd.thr; d.n_keys = jd.key_codes.size();
-        d.key_codes = jd.key_codes.data(); d.row_offsets = jd.row_offsets.data(); d.branch_ids = jd.branch_ids.data(); d.scores = jd.scores.data();
+        if (!uniondb.empty()) {
+            ud = rkh::load_uniondb(slurp(uniondb));
+            tree = ud.tree;
+            d.alphabet = ud.alphabet == 4 ? RK_ALPHABET_DNA : RK_ALPHABET_AA; d.convert_uo = ud.convert_uo ? 1 : 0; d.k = ud.k;
+            d.thr_log10 = ud.thr_log10; d.thr = ud.thr; d.n_keys = ud.key_codes.size();
+            d.key_codes = ud.key_codes.data(); d.row_offsets = ud.row_offsets.data(); d.branch_ids = ud.branch_ids.data(); d.scores = ud.scores.data();
+        } else {
+            jd = rkh::load_jsondb(slurp(jsondb));
+            tree = rkh::parse_newick(jd.original_tree);
+            d.alphabet = RK_ALPHABET_DNA; d.k = jd.k;
+            d.thr_log10 = jd.thr_log10; d.thr = jd.thr; d.n_keys = jd.key_codes.size();
+            d.key_codes = jd.key_codes.data(); d.row_offsets = jd.row_offsets.data(); d.branch_ids = jd.branch_ids.data(); d.scores = jd.scores.data();
+        }
+        d.n_branches = (uint32_t)tree.nodes.size();
         d.device = device; d.table_mode = RK_TABLE_AUTO;
         rk_db *db = nullptr;
         if (rk_db_create(&d, &db) != RK_OK) throw std::runtime_error(std::string("rk_db_create: ") + rk_last_error());

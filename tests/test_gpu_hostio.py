@@ -165,3 +165,14 @@ def test_place_tool_accepts_a_union_database(tmp_path):
     u = json.loads((tmp_path / "u.jplace").read_text())
     j = json.loads((tmp_path / "j.jplace").read_text())
     assert u["placements"] == j["placements"] and u["tree"] == j["tree"] and len(u["placements"]) > 100
+    # the native driver reads the same file (rk_javaser.hpp): byte-identical .jplace
+    import subprocess
+    from rappas_amd import build
+    args = ["--uniondb", str(tmp_path / "DB.union"), "--out", str(tmp_path / "u.jplace")] + common
+    py = (tmp_path / "u.jplace").read_bytes()
+    assert place_tool.main(args) == 0
+    py = (tmp_path / "u.jplace").read_bytes()
+    (tmp_path / "u.jplace").unlink()
+    r = subprocess.run([build.build_host_tools()] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "u.jplace").read_bytes() == py

@@ -109,3 +109,55 @@ def test_native_loader_reads_the_fixture_authored_from_the_java(rk_place):
         f"{code('GAT')} 1:-1.2041199 3:-0.69897",
         f"{code('CGA')} 4:-9.765625E-4",
     ]
+
+
+def _union_dump(d):
+    """what `rk_place --load-uniondb` prints, from the Python reader's result"""
+    t = d["tree"]
+    f = hostio.java_float_to_string
+    head = (f"{d['alphabet']} {d['k']} {int(d['convert_uo'])} {int(d['only_fakes'])} {f(d['thr'])} {f(d['thr_log10'])} {f(np.float32(d['omega']))} "
+            f"{f(np.float32(d['calibration']))} {len(d['key_codes'])} {len(d['scores'])}")
+    lines = [head, t.jplace_newick()]
+    lines += [f"{n.id}\t{n.label}\t{n.jplace_edge}\t{n.parent.id if n.parent is not None else -1}" for n in t.nodes]
+    for r in range(len(d["key_codes"])):
+        a, b = int(d["row_offsets"][r]), int(d["row_offsets"][r + 1])
+        ent = "".join(f" {int(d['branch_ids'][e])}:{f(d['scores'][e])}" for e in range(a, b))
+        lines.append(f"{int(d['key_codes'][r])}{ent}")
+    return "\n".join(lines) + "\n"
+
+
+def test_union_reader_matches_its_python_twin(rk_place, tmp_path):
+    """rk_javaser.hpp + load_uniondb (C++) against rappas_amd/javaser.py + hostio.load_uniondb on streams assembled from the
+    serialization specification (tests/javaser_writer.py): DNA and protein sessions, a larger random tree, back references,
+    the Swing classes the tree drags in.  Both readers are unpinned (no JVM here): this only shows they agree."""
+    from tests import javaser_writer as JW
+    from tests import test_uniondb as TU
+    streams = {"toy": TU.toy_stream()}
+    nodes = [(0, "r", -1.0, 2, None), (1, "x", 0.5, 0, 0), (2, "y", 0.25, 1, 0)]
+    rows = [(bytes([0, 19, 7]), [(1, -2.5)]), (bytes([9, 9, 14]), [(2, -0.25), (1, -3.0)])]
+    for uo in (False, True):
+        streams[f"aa{int(uo)}"] = JW.union_stream(20, 3, 1.5, 4.21875e-4, -3.3748, JW.phylo_tree(nodes, True), rows, convert_uo=uo)
+    db = synth.make_db(4, 6, 75, 800, 6000, seed=21)
+    tree = hostio.parse_newick(synth.make_newick(75, seed=6))
+    spec = [(n.id, n.label, float(n.bl), n.jplace_edge, n.parent.id if n.parent is not None else None) for n in tree.nodes]
+    big = []
+    for r, code in enumerate(db.key_codes.tolist()):
+        a, b = int(db.row_offsets[r]), int(db.row_offsets[r + 1])
+        big.append((int(code).to_bytes(2, "little"), [(int(db.branch_ids[e]), float(db.scores[e])) for e in range(a, b)]))
+    streams["big"] = JW.union_stream(4, 6, 1.5, float(db.thr), float(db.thr_log10), JW.phylo_tree(spec, tree.rooted), big)
+    for name, blob in streams.items():
+        f = tmp_path / f"{name}.union"
+        f.write_bytes(blob)
+        assert run(rk_place, "--load-uniondb", str(f)) == _union_dump(hostio.load_uniondb(blob)), name
+
+
+def test_union_reader_rejects_what_is_not_a_union(rk_place, tmp_path):
+    from tests import test_uniondb as TU
+    good = TU.toy_stream()
+    for name, blob in (("magic", b"\x00\x01\x02\x03" + good[4:]), ("cut", good[:len(good) // 2]), ("empty", b"")):
+        f = tmp_path / f"{name}.union"
+        f.write_bytes(blob)
+        r = subprocess.run([rk_place, "--load-uniondb", str(f)], capture_output=True, text=True)
+        assert r.returncode == 1 and "rk_place:" in r.stderr, (name, r.stderr)
+        with pytest.raises(ValueError):
+            hostio.load_uniondb(blob)
