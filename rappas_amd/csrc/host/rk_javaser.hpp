@@ -223,6 +223,7 @@ class Reader {
             const int32_t n = i4();
             if (n < 0) throw Error("negative array length", at);
             const char t = a->desc->name.size() > 1 ? a->desc->name[1] : '?';
+            if ((size_t)n > n_ - p_) throw Error("array longer than what is left of the stream", at);  // (every element takes >= 1 byte)
             if (t == 'B') {
                 const uint8_t *raw = take((size_t)n);
                 a->s.assign((const char *)raw, (size_t)n);  // byte[]: kept as bytes (k-mer keys)

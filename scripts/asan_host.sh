@@ -24,9 +24,24 @@ python - "$T" <<'PY'
 import sys
 from rappas_amd import hostio, synth
 open(sys.argv[1] + "/db.json", "w").write(hostio.dump_jsondb(synth.make_db(4, 5, 9, 150, 700, seed=5), synth.make_newick(9, seed=1)))
+from tests import test_uniondb as TU
+blob = TU.toy_stream()
+open(sys.argv[1] + "/toy.union", "wb").write(blob)
+for cut in range(0, len(blob), 7):  # every seventh truncation of the stream: the reader has to stop with an error, not read past it
+    open(sys.argv[1] + f"/cut{cut}.union", "wb").write(blob[:cut])
+import random
+rnd = random.Random(1)
+for i in range(60):  # single-byte corruptions
+    b = bytearray(blob)
+    b[rnd.randrange(len(b))] = rnd.randrange(256)
+    open(sys.argv[1] + f"/flip{i}.union", "wb").write(bytes(b))
 PY
-for args in "--emit-tree $T/t.nwk" "--dedup $T/q.fa" "--load-jsondb $T/db.json" "--format-float 0.1" "--format-double 1e-300" "--md5 abc"; do
+for args in "--emit-tree $T/t.nwk" "--dedup $T/q.fa" "--load-jsondb $T/db.json" "--load-uniondb $T/toy.union" "--format-float 0.1" "--format-double 1e-300" "--md5 abc"; do
   ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 /tmp/rk_place_asan $args > /dev/null
+done
+for f in $T/cut*.union $T/flip*.union; do  # exit 0 (still a valid stream) or 1 (rejected); anything else is a sanitizer report or a crash
+  rc=0; ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 /tmp/rk_place_asan --load-uniondb $f > /dev/null 2>$T/err || rc=$?
+  if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "union reader: $f -> exit $rc"; cat $T/err | head -20; exit 1; fi
 done
 rm -rf $T
 echo "asan/ubsan native host side: OK"
