@@ -1207,7 +1207,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     probe.words_per_read = 16;
     // (the tile-pipelined variant serves packed records of <= 16 words, i.e. reads of <= 256 bases / 102 residues; longer
     // records take place_packed_kernel with the same geometry)
-    snprintf(buf, sizeof(buf), "%s<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU=%u",
+    snprintf(buf, sizeof(buf), "%s<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU<=%u (LDS; registers may allow fewer)",
              use_pipelined16(db, g, probe) ? "place_packed16_kernel" : "place_packed_kernel", g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
              db->info.rows_bytes < ROWS_FIT32_LIMIT ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
