@@ -47,6 +47,12 @@ if prefix:
             fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
             write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
             meta = json.loads(os.environ.get("PROF_META", "{}"))
+            if not meta:  # what was profiled: from the bench line profile.sh keeps of its timing pass
+                try:
+                    bl = json.loads(open(os.path.join(os.path.dirname(out.rstrip("/")), os.path.basename(out.rstrip("/")) + "_bench_line.json")).read())
+                    meta = {"config": bl["config"]["workload"].split(":")[0], "reads": bl["config"]["reads_per_gpu"]}
+                except Exception:
+                    meta = {}
             miss = sum(d["TCC_MISS_sum"]) / len(d["TCC_MISS_sum"]) if "TCC_MISS_sum" in d else None
             meta.update({"kernel": k, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
                          "TCC_MISS_per_launch": miss,
