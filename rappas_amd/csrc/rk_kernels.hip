@@ -2183,6 +2183,9 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     for (u32 i = lane; i < a.s_stride; i += 64) S[i] = S_UNTOUCHED;
     for (u32 i = lane; i < chunk; i += 64) { Samb[i] = 0.0f; Camb[i] = 0; }
     wave_lds_fence();
+#ifdef RK_STAMPS
+    unsigned long long st_[16] = {0}, t_ = rk_now();
+#endif
 
     for (u64 r0 = (u64)blockIdx.x * 64; r0 < a.n_reads; r0 += (u64)gridDim.x * 64) {
         // each lane inspects one read's flag; the wave then serves the flagged ones in turn
@@ -2242,12 +2245,21 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     const bool inr = j < Q;
                     u64 code = 0;      // ambiguous positions contribute state 0
                     u32 ambmask = 0;   // bit i <=> window position i is ambiguous
-                    if (inr) {
+                    {
+                        // every lane decodes two characters of the batch's 64 + k - 1 (its own position and, for the first k - 1
+                        // lanes, the one 64 further on); a k-mer's other characters come from the neighbouring lanes
+                        const u32 ia = j0 + lane, ib = j0 + 64 + lane;
+                        const u32 ca = ia < R ? m.char_table[s[ia]] : 0u;
+                        const u32 cb = (lane + 1 < k && ib < R) ? m.char_table[s[ib]] : 0u;
+                        const u32 pair = ca | (cb << 8);
                         for (u32 i = 0; i < k; i++) {
-                            const u32 c = m.char_table[s[j + i]];
+                            const u32 src = lane + i;
+                            const u32 got = (u32)__shfl((int)pair, (int)(src & 63u), 64);
+                            const u32 c = (src < 64u ? got : got >> 8) & 0xFFu;
                             code |= (u64)((c & 0x80) ? 0u : c) << (BITS * i);
                             ambmask |= ((c >> 7) & 1u) << i;
                         }
+                        if (!inr) { code = 0; ambmask = 0; }
                     }
                     u64 desc = 0;
                     if (inr && ambmask == 0) desc = lookup_desc<BITS, TM>(a.db, code);
@@ -2271,6 +2283,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     u64 amb_b = __ballot(inr && ambmask != 0);
                     const u64 hit_b = __ballot(hit);
                     u32 p0 = 0;
+                    RK_STAMP(1);  // decode + probes of the batch
                     while (true) {  // wave-uniform: runs of unambiguous positions separated by ambiguous ones
                         const u32 na = amb_b ? (u32)__builtin_ctzll(amb_b) : 64u;
                         const u64 below_na = na >= 64 ? ~0ull : ((1ull << na) - 1);
@@ -2280,8 +2293,10 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         if ((hb >> lane) & 1ull) clist[cnt + __builtin_popcountll(hb & ((1ull << lane) - 1))] = desc;
                         cnt += nh;
                         any_long = any_long || __any(((hb >> lane) & 1ull) && ((u32)desc & DESC_LEN_MASK) > 64u);
+                        RK_STAMP(2);  // list building
                         if (na >= 64) break;
                         flush();  // everything before the ambiguous k-mer must be applied first
+                        RK_STAMP(3);  // flush (accumulate)
                         const u32 maskA = (u32)__builtin_amdgcn_readlane((int)ambmask, (int)na);
                         const u32 clo = (u32)__builtin_amdgcn_readlane((int)(u32)code, (int)na);
                         const u32 chi = (u32)__builtin_amdgcn_readlane((int)(u32)(code >> 32), (int)na);
@@ -2300,6 +2315,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                                          (u32)__builtin_amdgcn_readlane((int)(u32)alt_d[w], (int)na);
                             if (!(RK_ABLATE & 128)) amb_position<BITS, TM>(a, m, S, Samb, Camb, chunk, codeA, p, cls, lane, QT, have_pre, pre, s_lo, nb, p2, cls2);
                         }
+                        RK_STAMP(4);  // ambiguous position
                         amb_b &= amb_b - 1;
                         p0 = na + 1;
                         if (p0 >= 64) break;
@@ -2308,10 +2324,9 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                 flush();
                 wave_lds_fence();
                 u64 win_key;
-#ifdef RK_STAMPS
-                unsigned long long st_[16] = {0}, t_ = 0;
-#endif
+                RK_STAMP(3);  // last flush
                 select_topk<64>(S, nb, lane, 0u, K, clist, ASCII_LIST_CAP, win_key RK_STAMP_ARGS);
+                RK_STAMP(5);
                 wave_lds_fence();
                 if (win_key != 0) win_key -= s_lo;  // the key's low 16 bits hold 0xFFFF - branch: window-relative -> tree id
                 if (n_win == 1) {
@@ -2327,8 +2342,17 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
             }
             const int numBest = __builtin_popcountll(__ballot(acc_key != 0));
             weigh_and_store<64>(a, r, lane, numBest, acc_key, flags);
+            RK_STAMP(6);
+#ifdef RK_STAMPS
+            st_[10] += 1;
+#endif
         }
+        RK_STAMP(0);  // flag inspection, idle lanes
     }
+#ifdef RK_STAMPS
+    if (lane == 0 && blockIdx.x < 4096)
+        for (int i = 0; i < 16; i++) rk_stamp_buf[blockIdx.x * 16 + i] = st_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
