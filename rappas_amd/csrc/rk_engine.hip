@@ -907,7 +907,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         // 999 branches: 16 lanes (8 waves) 335 Mreads/s; 1300 / 1500: 16 lanes (6 waves) 219 / 214 vs 32 lanes (11 / 10 waves) 156 / 141;
         // 1999: 32 lanes (8 waves) 199 vs 16 lanes (4 waves) 165 vs 64 lanes 120; 3999: 32 lanes (4 waves) 88 vs 64 lanes (9 waves) 62;
         // 7999: 64 lanes (4 waves) 46 vs 32 lanes (2 waves) 35.  (Between 1 117 and 16 000 branches these dense geometries only serve
-        // what the windowed kernel does not take: keep_at_most > 8, records of more than 16 words, a forced lane width.)
+        // what the windowed kernel does not take: records of more than 16 words, a forced lane width.)
         G = 64;
         if (keep_at_most <= 16 && bytes_for(16, 16 + 3 * RK_RING + 40) <= db->lds_per_cu / 6) G = 16;
         else if (keep_at_most <= 32 && bytes_for(32, 32 + 3 * RK_RING + 40) <= db->lds_per_cu / 4) G = 32;
@@ -989,17 +989,26 @@ static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipS
     return db->info.bits_per_symbol == 2 ? launch_t<G, 2>(db, g, a, s) : launch_t<G, 5>(db, g, a, s);
 }
 // mid-size trees: the windowed kernel whenever the image carries window spans, nobody forced a lane-group width, the K best
-// of two windows fit one 16-lane row (keep_at_most <= 8) and the packed record fits one word per lane
+// of the tree fit one 16-lane row (keep_at_most <= 16) and the packed record fits one word per lane
 static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_per_read) {
     static const bool off = getenv("RK_NO_WINDOW") != nullptr;  // developer knob: A/B against the dense kernels
-    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 8 && words_per_read <= 16;
+    // (scripts/keep_at_most_sweep.py, windowed against dense, Mreads/s: 3 999 branches K = 9 / 12 / 16: 149 / 124 / 57 against 69 / 67 / 61;
+    // 7 999: 99 / 76 / 37 against 37 / 36 / 35 -- with 13+ winners a stream of the fast select drops a candidate on most tiles)
+    const bool pays = keep_at_most <= 12 || db->info.n_branches >= 6000;
+    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && pays && words_per_read <= 16;
 }
 
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     WindowPlan wp = db->wp;
-    if (a.words_per_read > 10 && wp.work_cap > 88) {  // reads beyond ~160 bases: a whole read in the main list matters more than one accumulate call per window
-        wp.main_cap += wp.work_cap - 88;
-        wp.work_cap = 88;
+    // 88 words = the 44 keys the exact select of a window needs as scratch for keep_at_most <= 8 (K + 16 candidates + 16 winners); 96 beyond
+    const uint32_t work_min = a.keep_at_most > 8 ? 96u : 88u;
+    if (wp.work_cap < work_min) {
+        wp.main_cap -= work_min - wp.work_cap;
+        wp.work_cap = work_min;
+    }
+    if (a.words_per_read > 10 && wp.work_cap > work_min) {  // reads beyond ~160 bases: a whole read in the main list matters more than one accumulate call per window
+        wp.main_cap += wp.work_cap - work_min;
+        wp.work_cap = work_min;
     }
     a.s_stride = wp.s_stride; a.main_cap = wp.main_cap; a.work_cap = wp.work_cap; a.list_cap = wp.work_cap / 2;
     const size_t lds_wave = (size_t)4 * (wp.s_stride + wp.main_cap + wp.work_cap) * 4;

@@ -1381,7 +1381,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
     const u32 nb = a.db.n_branches, k = a.db.k;
     const u32 W = a.db.win_w, NWIN = a.db.n_win;
     const float T = a.db.T;
-    const int K = (int)a.keep_at_most;  // <= 8 (the host picks the dense kernels otherwise)
+    const int K = (int)a.keep_at_most;  // <= 16 = one winner per lane (the host picks the dense kernels otherwise)
     const u64 gmask = (1ull << G) - 1;
     const u64 gmask_mine = gmask << (gi * G);  // this lane's group inside a wave ballot
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
@@ -1652,15 +1652,35 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     if (!(RK_ABLATE & 1024) || w + 1 == NWIN) select_topk<G>(S, win_n, li, gi, K, work64, (int)(a.work_cap / 2), win_key RK_STAMP_ARGS);  // (timing only)
                     wave_lds_fence();
                     if (win_key != 0ull) win_key -= (u64)wlo;  // window-relative branch -> tree id (low 16 bits hold 0xFFFF - branch)
-                    const u64 moved = ((u64)row_ror32<8>((u32)(win_key >> 32)) << 32) | row_ror32<8>((u32)win_key);  // lane r -> lane r + 8
-                    const u64 comb = li < 8 ? acc_key : moved;
-                    const int rank = RankAbove<G, G - 1>::run(comb, li);
-                    work64[li] = 0ull;
-                    wave_lds_fence();
-                    if (comb != 0ull && rank < K) work64[rank] = comb;
-                    wave_lds_fence();
-                    acc_key = (int)li < K ? work64[li] : 0ull;
-                    wave_lds_fence();
+                    if (K <= 8) {  // both sets fit the 16 lanes: ranks by counting over lane rotations
+                        const u64 moved = ((u64)row_ror32<8>((u32)(win_key >> 32)) << 32) | row_ror32<8>((u32)win_key);  // lane r -> lane r + 8
+                        const u64 comb = li < 8 ? acc_key : moved;
+                        const int rank = RankAbove<G, G - 1>::run(comb, li);
+                        work64[li] = 0ull;
+                        wave_lds_fence();
+                        if (comb != 0ull && rank < K) work64[rank] = comb;
+                        wave_lds_fence();
+                        acc_key = (int)li < K ? work64[li] : 0ull;
+                        wave_lds_fence();
+                    } else {  // up to 32 candidates through the LDS: every lane ranks its two against all, then the list is rewritten by rank
+                        work64[li] = acc_key;
+                        work64[G + li] = win_key;
+                        wave_lds_fence();
+                        int rank_a = 0, rank_w = 0;
+                        for (int t = 0; t < 2 * G; t++) {
+                            const u64 o = work64[t];
+                            rank_a += o > acc_key ? 1 : 0;
+                            rank_w += o > win_key ? 1 : 0;
+                        }
+                        wave_lds_fence();
+                        work64[li] = 0ull;
+                        wave_lds_fence();
+                        if (acc_key != 0ull && rank_a < K) work64[rank_a] = acc_key;  // (keys are unique: no two candidates share a rank)
+                        if (win_key != 0ull && rank_w < K) work64[rank_w] = win_key;
+                        wave_lds_fence();
+                        acc_key = (int)li < K ? work64[li] : 0ull;
+                        wave_lds_fence();
+                    }
                 }
             }
             if (phase == 0) {

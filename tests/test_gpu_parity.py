@@ -698,8 +698,21 @@ def test_windowed_kernel_protein_and_keep_at_most():
     sdb = synth.make_db(20, 3, 3100, 6000, 60000, seed=6)
     odb = O.OracleDB.from_synth(sdb)
     seq, off = synth.make_reads(20, 1500, 100, seed=1, amb_rate=0.002, var_len=30)
-    for K in (1, 8, 9, 16):  # 9 and 16 do not fit the window merge: the dense kernels serve them
+    for K in (1, 8, 9, 16):  # beyond 8 the windows' winners are merged through the LDS instead of lane rotations
         run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0001)
+
+
+@pytest.mark.parametrize("K", [9, 12, 16])
+@pytest.mark.parametrize("n_branches", [1500, 7999, 15999])
+def test_windowed_kernel_keep_at_most_beyond_eight(n_branches, K):
+    """scattered and clade-shaped reads: the fast pass, the exact pass (a stream drops candidates far more often with 16 winners) and
+    the merge of two sets of up to 16 winners"""
+    sdb = synth.make_db(4, 8, n_branches, 40000, 520000, seed=n_branches + K)
+    seq, off = synth.make_reads(4, 1500, 150, seed=K, amb_rate=0.001, var_len=60)
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0)
+    cdb, genome = _clade_db(9, n_branches, 6000, seed=K)
+    seq, off = synth.make_motif_reads(genome, 1200, 150, seed=K, var_len=30)
+    run_case(cdb, O.OracleDB.from_synth(cdb), seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0)
 
 
 def test_windowed_and_dense_kernels_agree(monkeypatch):
