@@ -992,10 +992,8 @@ static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipS
 // of the tree fit one 16-lane row (keep_at_most <= 16) and the packed record fits one word per lane
 static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_per_read) {
     static const bool off = getenv("RK_NO_WINDOW") != nullptr;  // developer knob: A/B against the dense kernels
-    // (scripts/keep_at_most_sweep.py, windowed against dense, Mreads/s: 3 999 branches K = 9 / 12 / 16: 149 / 124 / 57 against 69 / 67 / 61;
-    // 7 999: 99 / 76 / 37 against 37 / 36 / 35 -- with 13+ winners a stream of the fast select drops a candidate on most tiles)
-    const bool pays = keep_at_most <= 12 || db->info.n_branches >= 6000;
-    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && pays && words_per_read <= 16;
+    // (scripts/keep_at_most_sweep.py, windowed against dense, Mreads/s: 3 999 branches K = 9 / 12 / 16: 156 / 141 / 105 against 91 / 84 / 76)
+    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && words_per_read <= 16;
 }
 
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {

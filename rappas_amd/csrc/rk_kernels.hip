@@ -21,6 +21,9 @@
 #ifndef RK_ROW_NT
 #define RK_ROW_NT 0
 #endif
+#ifndef RK_HEADS_MAX_K
+#define RK_HEADS_MAX_K 16  // the fast select (stream heads) up to this keep_at_most (C2: K = 9 ... 16 run at 343 ... 274 Mreads/s with it, 280 ... 117 through the exact two-pass scan)
+#endif
 #ifndef RK_ABLATE
 #define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate, 512 / 1024 / 2048 = windowed kernel without accumulate / with the exact select only in the last window / without compaction and accumulate (outputs are then wrong), 4096 = windowed kernel without skipping untouched windows (outputs stay right)
 #endif
@@ -726,7 +729,7 @@ __device__ __forceinline__ int select_topk(u32 *S, u32 n_branches, u32 li, u32 g
     if (li == 0) S[0] = S_UNTOUCHED;
     wave_lds_fence();
     const u32 nb = n_branches + 1;
-    if (K > 8) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
+    if (K > RK_HEADS_MAX_K || K > G) return select_topk_scan<G>(S, nb, li, gi, K, list, cap, win_key RK_STAMP_ARGS);
     Heads4 h;
     heads_clear(h);
     heads_scan<G>(S, nb, li, 0u, h);

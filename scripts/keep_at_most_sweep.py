@@ -6,14 +6,14 @@ import rappas_amd as ra
 from rappas_amd import synth
 n = 2_000_000
 mode = "dense   " if os.environ.get("RK_NO_WINDOW") else "windowed"
-for nb in (3999, 7999):
+for nb in [int(x) for x in sys.argv[1:]] or (3999, 7999):
     sdb = synth.make_db(4, 10, nb, 786432, 10_000_000, seed=42)
     db = ra.PhyloKmerDB.from_synth(sdb)
     pp = ra.PlacementProcess(db)
     wpr = db.packed_words(150)
     packed = torch.randint(-2**31, 2**31, (n, wpr), dtype=torch.int64, device="cuda").to(torch.int32)
     packed[:, wpr - 1] &= (1 << (300 - 32 * (wpr - 1))) - 1
-    for K in (7, 8, 9, 12, 16):
+    for K in (7, 8, 9, 12, 14, 16):
         out = pp.place_packed(packed, fixed_len=150, keepAtMost=K); torch.cuda.synchronize()
         t = time.time()
         for _ in range(3):
