@@ -21,6 +21,9 @@
 #ifndef RK_ROW_NT
 #define RK_ROW_NT 0
 #endif
+#ifndef RK_ROW_AUX
+#define RK_ROW_AUX 0  // cache-policy bits of the row-unit loads (developer A/B: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #ifndef RK_HEADS_MAX_K
 #define RK_HEADS_MAX_K 16  // the fast select (stream heads) up to this keep_at_most (C2: K = 9 ... 16 run at 343 ... 274 Mreads/s with it, 280 ... 117 through the exact two-pass scan)
 #endif
@@ -419,7 +422,7 @@ __device__ __forceinline__ void accumulate_units(u32 *S, const u32 *items, int w
         u32 off = item + li8;  // G == 16: the low bits of an item are zero
         if (G > 16) off = (my_unit <= (item & 7u)) ? (item & ~127u) + li8 : ITEM_FILLER;
         if (RK_ABLATE & 16) off = li8;
-        const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+        const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, RK_ROW_AUX);
         b = e.x;  // (left untouched until its step: anything computed from it here would wait for the load and serialise the ring)
         v = __uint_as_float(e.y);
     };
