@@ -39,7 +39,8 @@ constexpr u32 S_UNTOUCHED = 0xFF800000u;
 
 struct DbView {
     const u64 *direct;   // [sigma^k] row descriptors (RK_TABLE_DIRECT8) or nullptr
-    const uint4 *compact;  // [ceil(sigma^k/12)] blocks {u32 first unit, 12 x u8 units} (RK_TABLE_DIRECT) or nullptr
+    const uint4 *compact;  // RK_TABLE_DIRECT: [ceil(sigma^k/12)] blocks {u32 first unit, 12 x u8 units}, or -- compact_nib -- [ceil(sigma^k/24)] blocks
+                           // {u32 first unit, 24 x u4 units} when no row exceeds 15 units; nullptr otherwise
     const uint4 *slots;  // [hash_mask+1] {key+1 lo, key+1 hi, desc lo, desc hi} (RK_TABLE_HASH) or nullptr
     u64 hash_mask;
     const unsigned char *rows;
@@ -47,6 +48,7 @@ struct DbView {
     u32 k, bits, n_branches, alphabet;
     float T, P;
     u32 convert_uo;
+    u32 compact_nib;  // the compact table holds 4-bit unit counts, 24 k-mers per block (half the table: its lines stay in the L2)
     u32 mono;  // every score >= T (all increments >= 0): first touch of a branch can be a max with the -inf marker
     u32 soa;  // large-tree (indexed) images: a row is u16 branch[len] followed by f32 score[len] (6 bytes per entry)
     // mid-size trees (place_packed16w_kernel): the tree is cut into n_win windows of win_w branches; winspec[dense k-mer index] =

@@ -271,6 +271,7 @@ struct rk_db {
     unsigned char *d_alpha = nullptr;  // table[256] | alts[320] | alt_count[16]
     unsigned char *d_winspec = nullptr;  // [sigma^k] window span per k-mer (windowed images only)
     bool windowed = false;
+    bool compact_nib = false;          // the compact table holds 4-bit unit counts
     WindowPlan wp;
     uint32_t lanes_per_read = 0;       // 0 = auto
     uint32_t waves_per_block = 1;
@@ -369,6 +370,7 @@ static void finish_db(rk_db *db, const DbMeta &m, uint32_t mode, bool indexed, b
     db->info.max_row_len = max_len;
     db->view.direct = mode == RK_TABLE_DIRECT8 ? (const u64 *)db->d_table : nullptr;
     db->view.compact = mode == RK_TABLE_DIRECT ? (const uint4 *)db->d_table : nullptr;
+    db->view.compact_nib = db->compact_nib ? 1u : 0u;
     db->view.slots = mode == RK_TABLE_HASH ? (const uint4 *)db->d_table : nullptr;
     db->view.hash_mask = hash_mask;
     db->view.rows = (const unsigned char *)db->d_rows;
@@ -393,22 +395,31 @@ static int check_launchable(const rk_db *db);
 // HASH    : open addressing, linear probing, 16-byte slots {key+1, descriptor}, load <= 0.5.
 template <class FDense, class FDesc, class FCode>
 static int build_table(uint32_t &mode, uint64_t space, uint64_t n_keys, bool indexed, uint64_t max_units, uint64_t blob_units,
-                       FDense dense_of, FDesc desc_of, FCode code_of, std::vector<uint64_t> &table, uint64_t &slots, uint64_t &hash_mask) {
+                       FDense dense_of, FDesc desc_of, FCode code_of, std::vector<uint64_t> &table, uint64_t &slots, uint64_t &hash_mask,
+                       bool &nib) {
     if (mode == RK_TABLE_DIRECT && (max_units > 255 || blob_units >= (1ull << 32) || indexed)) mode = RK_TABLE_DIRECT8;
     slots = 0; hash_mask = 0;
+    // 4-bit unit counts (24 k-mers per block, 0.67 bytes per k-mer) whenever no row exceeds 15 units = 240 entries: half the table
+    // means its lines are re-touched twice as often and survive the rows streaming through the same L2 sets (C2: 15 of a read's 141
+    // probes missed the L2 with the byte form)
+    static const bool bytes_only = getenv("RK_COMPACT_BYTES") != nullptr;  // developer knob: A/B against the byte form
+    nib = mode == RK_TABLE_DIRECT && max_units <= 15 && !bytes_only;
     try {
         if (mode == RK_TABLE_DIRECT) {
             slots = space;
-            const uint64_t n_blocks = (space + COMPACT_KMERS - 1) / COMPACT_KMERS;
+            const uint64_t per = nib ? 2 * COMPACT_KMERS : COMPACT_KMERS;
+            const uint64_t n_blocks = (space + per - 1) / per;
             table.assign(n_blocks * 2, 0);
             unsigned char *tb = (unsigned char *)table.data();
             uint64_t next_unit = 1, ki = 0;
             for (uint64_t blk = 0; blk < n_blocks; blk++) {
                 const uint32_t base32 = (uint32_t)next_unit;
                 memcpy(tb + blk * 16, &base32, 4);
-                while (ki < n_keys && dense_of(ki) / COMPACT_KMERS == blk) {
+                while (ki < n_keys && dense_of(ki) / per == blk) {
                     const uint64_t units = ((uint32_t)desc_of(ki) & DESC_LEN_MASK) / ROW_UNIT;
-                    tb[blk * 16 + 4 + (dense_of(ki) % COMPACT_KMERS)] = (unsigned char)units;
+                    const uint64_t j = dense_of(ki) % per;
+                    if (nib) tb[blk * 16 + 4 + j / 2] |= (unsigned char)(units << (4 * (j & 1)));
+                    else tb[blk * 16 + 4 + j] = (unsigned char)units;
                     next_unit += units;
                     ki++;
                 }
@@ -444,6 +455,7 @@ struct DbImage {
     uint64_t n_keys = 0, n_entries = 0, blob_bytes = 0, slots = 0, hash_mask = 0;
     std::vector<Entry> blob;
     std::vector<uint64_t> table;
+    bool nib = false;                   // compact table in its 4-bit form
     bool windowed = false;              // place_packed16w_kernel can serve this image
     WindowPlan wp;
     std::vector<unsigned char> winspec;  // [sigma^k]
@@ -646,7 +658,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     {
         int rc = build_table(img.mode, space, n_keys, indexed, max_units, blob_units,
                              [&](uint64_t i) { return order[i].first; }, [&](uint64_t i) { return desc[order[i].second]; },
-                             [&](uint64_t i) { return d->key_codes[order[i].second]; }, img.table, img.slots, img.hash_mask);
+                             [&](uint64_t i) { return d->key_codes[order[i].second]; }, img.table, img.slots, img.hash_mask, img.nib);
         if (rc) return rc;
     }
 
@@ -719,6 +731,7 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
         db->wp = img.wp;
     }
 #undef DB_TRY
+    db->compact_nib = img.nib;
     finish_db(db, meta, mode, indexed, img.mono, n_keys, n_entries, slots, hash_mask, table_bytes, blob_bytes, max_len);
     rc = check_launchable(db);  // a tree whose score vector no kernel geometry can hold is refused here, not at the first batch
     if (rc) { rk_db_destroy(db); return rc; }
@@ -766,6 +779,7 @@ extern "C" int rk_db_clone(const rk_db *src, int32_t device, rk_db **out) {
     }
     CL_TRY(hipDeviceSynchronize());
 #undef CL_TRY
+    db->compact_nib = src->compact_nib;
     finish_db(db, meta, src->info.table_mode, src->indexed, src->view.mono != 0, src->info.n_keys, src->info.n_entries, src->info.table_slots,
               src->view.hash_mask, table_bytes, blob_bytes, src->info.max_row_len);
     db->lanes_per_read = src->lanes_per_read;
@@ -1215,7 +1229,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     // (the tile-pipelined variant serves packed records of <= 16 words, i.e. reads of <= 256 bases / 102 residues; longer
     // records take place_packed_kernel with the same geometry)
     snprintf(buf, sizeof(buf), "%s<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU<=%u (LDS; registers may allow fewer)",
-             use_pipelined16(db, g, probe) ? "place_packed16_kernel" : "place_packed_kernel", g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? "DIRECT" : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
+             use_pipelined16(db, g, probe) ? "place_packed16_kernel" : "place_packed_kernel", g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? (db->compact_nib ? "DIRECT4" : "DIRECT") : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
              db->info.rows_bytes < ROWS_FIT32_LIMIT ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();

@@ -153,7 +153,8 @@ __device__ __forceinline__ RawSlot lookup_fetch(const DbView &db, u64 code) {
     RawSlot r;
     if (TM == TM_COMPACT) {
         const u64 idx = dense_index<BITS>(code, db.k);
-        r.v = db.compact[(u32)(idx / COMPACT_KMERS)];
+        const u32 blk = (u32)(idx / COMPACT_KMERS);
+        r.v = db.compact[db.compact_nib ? blk >> 1 : blk];
     } else {  // TM_DIRECT8
         const uint2 d = *(const uint2 *)(db.direct + dense_index<BITS>(code, db.k));
         r.v = make_uint4(d.x, d.y, 0u, 0u);
@@ -169,6 +170,24 @@ __device__ __forceinline__ u64 lookup_decode(const DbView &db, const RawSlot &r,
         const u64 idx = dense_index<BITS>(code, db.k);
         const u32 i = (u32)(idx % COMPACT_KMERS);
         const uint4 n = r.v;
+        if (db.compact_nib) {
+            // the half-size form (no row of the database exceeds 15 units): {u32 first unit, 24 x u4 units per row}; k-mer i of the
+            // odd 12-block sits in the block's second half.  Nibble sums: even and odd nibbles through v_sad_u8 each.
+            const u32 j = i + ((u32)(idx / COMPACT_KMERS) & 1u) * COMPACT_KMERS;
+            auto nsum = [](u32 w, u32 acc) {
+                return __builtin_amdgcn_sad_u8(w & 0x0F0F0F0Fu, 0u, __builtin_amdgcn_sad_u8((w >> 4) & 0x0F0F0F0Fu, 0u, acc));
+            };
+            const u32 c0 = nsum(n.y, 0u);
+            const u32 c1 = nsum(n.z, c0);
+            const u32 word = j >> 3, sh = (j & 7u) * 4u;
+            const u32 wsel = word == 0 ? n.y : (word == 1 ? n.z : n.w);
+            const u32 csel = word == 0 ? 0u : (word == 1 ? c0 : c1);
+            const u32 prefix = nsum(wsel & ((1u << sh) - 1u), csel);
+            const u32 mine = (wsel >> sh) & 15u;
+            const u64 unit = (u64)n.x + prefix;
+            const u64 d = ((unit * ROW_UNIT) << DESC_LEN_BITS) | (u64)(mine * ROW_UNIT);
+            return d & (0ull - (u64)(mine != 0));
+        }
         const u32 c0 = __builtin_amdgcn_sad_u8(n.y, 0u, 0u);
         const u32 c1 = __builtin_amdgcn_sad_u8(n.z, 0u, c0);
         const u32 word = i >> 2, sh = (i & 3u) * 8u;

@@ -224,6 +224,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     if ((blob_bytes >> 3) >= (1ull << 40)) return fail(RK_ERR_UNSUPPORTED, "rk_db_create_synth: row blob exceeds 8 TiB");
     std::vector<uint64_t> table;
     uint64_t slots = 0, hash_mask = 0;
+    bool nib = false;
     {
         const uint32_t alphabet = d->alphabet, k = d->k;
         auto code_of = [&](uint64_t i) -> uint64_t {
@@ -233,7 +234,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
             return code;
         };
         int rc = build_table(mode, space, n_keys, indexed, max_units, blob_units, [&](uint64_t i) { return dense[i]; },
-                             [&](uint64_t i) { return desc[i]; }, code_of, table, slots, hash_mask);
+                             [&](uint64_t i) { return desc[i]; }, code_of, table, slots, hash_mask, nib);
         if (rc) return rc;
     }
 
@@ -287,6 +288,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
         SY_TRY(hipDeviceSynchronize());
     }
 #undef SY_TRY
+    db->compact_nib = nib;
     finish_db(db, meta, mode, indexed, /*mono=*/d->thr_log10 <= 0.0f, n_keys, n_entries, slots, hash_mask, table_bytes, blob_bytes, max_len);
     rc = check_launchable(db);
     if (rc) { rk_db_destroy(db); return rc; }

@@ -615,6 +615,44 @@ def test_mid_size_trees_take_the_windowed_kernel(n_branches, amb):
     assert st["placed"] > 2500
 
 
+@pytest.mark.parametrize("alphabet,k", [(4, 6), (20, 3)])
+@pytest.mark.parametrize("longest", [240, 241])
+def test_compact_table_in_its_half_size_and_byte_forms(alphabet, k, longest):
+    """DIRECT stores 4-bit unit counts (24 k-mers per 16-byte block) while no row exceeds 15 units = 240 entries, bytes (12 per
+    block) otherwise: every row read back through rk_db_fetch_row (the kernels' own lookup + decode), absent k-mers included, and
+    placements against the oracle, in both forms"""
+    nb = 700
+    sdb = synth.make_db(alphabet, k, nb, 2500, 40000, seed=longest + alphabet)
+    lens = (sdb.row_offsets[1:] - sdb.row_offsets[:-1]).astype(np.int64)
+    # rebuild with row lengths capped at `longest` and one row of exactly that length
+    lens = np.minimum(lens, 200)
+    lens[7] = longest
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    rng = np.random.default_rng(longest)
+    br = np.concatenate([np.sort(rng.choice(nb - 1, size=int(n), replace=False)) + 1 for n in lens]).astype(np.uint16)
+    sc = (sdb.thr_log10 * rng.random(int(off[-1]), dtype=np.float32)).astype(np.float32)
+    sdb = synth.SynthDB(alphabet, k, nb, sdb.thr, sdb.thr_log10, sdb.key_codes, off, br, sc, sdb.seed)
+    db = ra.PhyloKmerDB.from_synth(sdb, table_mode=ra.RK_TABLE_DIRECT)
+    try:
+        assert ("DIRECT4," in db.kernel_name()) == (longest <= 240), db.kernel_name()
+        present = {int(c): r for r, c in enumerate(sdb.key_codes.tolist())}
+        space = alphabet ** k
+        for dense in list(range(0, space, 7)) + [space - 1]:
+            code = int(synth.dense_to_code(alphabet, k, np.array([dense], dtype=np.uint64))[0])
+            b, v = db.fetch_row(code)
+            if code in present:
+                a, e = int(off[present[code]]), int(off[present[code] + 1])
+                order = np.argsort(b, kind="stable")
+                assert np.array_equal(b[order], br[a:e]) and np.array_equal(v[order].view(np.uint32), sc[a:e].view(np.uint32)), code
+            else:
+                assert len(b) == 0, code
+    finally:
+        db.close()
+    seq, off_r = synth.make_reads(alphabet, 1500, 120, seed=5, amb_rate=0.001, var_len=40)
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off_r, "direct", 0, "mean")
+
+
 def _clade_db(k, n_branches, genome_len, seed, mean_row=12.0, jitter=5):
     """keys = the k-mers of a random genome; the rows of the k-mers of one 500-bp stretch cover the same few dozen branches: reads cut
     from the genome pile their hits on one neighbourhood, so the K best branches are adjacent ids (a clade)"""
