@@ -102,7 +102,8 @@ def test_db_validate_builds_image_without_device():
     assert info.max_row_len == lens.max()
     units = ((lens + 15) // 16).sum() + 1                   # rows padded to whole 128-byte units + the reserved unit 0
     assert info.rows_bytes == units * 128
-    assert info.table_bytes == ((4 ** 8 + 11) // 12) * 16   # compact table: 16 bytes per 12 k-mers
+    per = 24 if lens.max() <= 240 else 12                    # compact table: 16 bytes per 24 k-mers (4-bit unit counts) while no row
+    assert info.table_bytes == ((4 ** 8 + per - 1) // per) * 16  # exceeds 15 units, per 12 k-mers (bytes) otherwise
     assert _validate(sdb, table_mode=_lib.RK_TABLE_DIRECT8).table_bytes == 4 ** 8 * 8
     h = _validate(sdb, table_mode=_lib.RK_TABLE_HASH)
     assert h.table_mode == _lib.RK_TABLE_HASH and h.table_slots >= 2 * sdb.n_keys and h.table_bytes == h.table_slots * 16
