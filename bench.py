@@ -309,7 +309,7 @@ def main():
             "config": {"workload": f"{a.config}: {'DNA' if alphabet == 4 else 'AA'} k={k}, {n_branches} branches, "
                                    f"phylo-kmer DB of {db_desc}, replicated per GPU; "
                                    f"{n_reads} x {rlen} symbol reads per GPU per step (uniform, seed 1+rank), keep_at_most=7",
-                       "table": {ra.RK_TABLE_DIRECT: "direct (compact 1.33 B/k-mer blocks)", ra.RK_TABLE_DIRECT8: "direct8", ra.RK_TABLE_HASH: "hash"}[db.info.table_mode],
+                       "table": {ra.RK_TABLE_DIRECT: "direct (compact blocks: 0.67 B/k-mer with 4-bit unit counts, 1.33 B/k-mer with bytes; see config.kernel)", ra.RK_TABLE_DIRECT8: "direct8", ra.RK_TABLE_HASH: "hash"}[db.info.table_mode],
                        "kernel": db.kernel_name(), "reads_per_gpu": n_reads, "sharding": f"reads x{n_gpus}, DB replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "bytes_per_read": B, "entries_per_read": H_mean,

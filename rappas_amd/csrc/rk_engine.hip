@@ -388,7 +388,7 @@ static int check_launchable(const rk_db *db);
 
 // ---- k-mer -> row descriptor table, keys given in ascending dense-index order through the accessors ----
 // DIRECT  : compact blocks, 16 bytes per 12 consecutive k-mers {u32 first row unit, 12 x u8 units per row}: 1.33 bytes
-//           per k-mer (1.4 MiB at k=10), small enough to live in the XCD L2s, one dwordx4 gather per probe; a row's
+//           per k-mer (1.4 MiB at k=10) -- or per 24 k-mers with 4-bit unit counts (see `nib` below) -- small enough to live in the XCD L2s, one dwordx4 gather per probe; a row's
 //           offset is the block base plus a byte prefix sum.  Needs rows of <= 255 units (4080 entries) and a blob
 //           of < 2^32 units (512 GiB); otherwise DIRECT falls back to DIRECT8.
 // DIRECT8 : one 8-byte descriptor per k-mer.
@@ -403,7 +403,9 @@ static int build_table(uint32_t &mode, uint64_t space, uint64_t n_keys, bool ind
     // means its lines are re-touched twice as often and survive the rows streaming through the same L2 sets (C2: 15 of a read's 141
     // probes missed the L2 with the byte form)
     static const bool bytes_only = getenv("RK_COMPACT_BYTES") != nullptr;  // developer knob: A/B against the byte form
-    nib = mode == RK_TABLE_DIRECT && max_units <= 15 && !bytes_only;
+    // ... where rows stream at all: with fewer than one row unit per two k-mer codes (C4: 0.13) the probes outnumber the row lines,
+    // nothing evicts the table and the longer decode is all that is left (C4: 5.37e8 against 5.52e8 reads/s)
+    nib = mode == RK_TABLE_DIRECT && max_units <= 15 && 2 * blob_units >= space && !bytes_only;
     try {
         if (mode == RK_TABLE_DIRECT) {
             slots = space;

@@ -622,7 +622,7 @@ def test_compact_table_in_its_half_size_and_byte_forms(alphabet, k, longest):
     block) otherwise: every row read back through rk_db_fetch_row (the kernels' own lookup + decode), absent k-mers included, and
     placements against the oracle, in both forms"""
     nb = 700
-    sdb = synth.make_db(alphabet, k, nb, 2500, 40000, seed=longest + alphabet)
+    sdb = synth.make_db(alphabet, k, nb, 2500 if alphabet == 4 else 6000, 16 * (2500 if alphabet == 4 else 6000), seed=longest + alphabet)
     lens = (sdb.row_offsets[1:] - sdb.row_offsets[:-1]).astype(np.int64)
     # rebuild with row lengths capped at `longest` and one row of exactly that length
     lens = np.minimum(lens, 200)
