@@ -28,7 +28,7 @@ using namespace rk;
 #endif
 #ifndef RK_WG_MIN_MEAN_ROW
 #define RK_WG_MIN_MEAN_ROW 64.0     // ... for rows at least this long on average ...
-#define RK_WG_ALWAYS_BRANCHES 16000u  // ... or, whatever the rows, above this many branches
+#define RK_WG_ALWAYS_BRANCHES 32000u  // ... or, whatever the rows, above this many branches (the windowed kernel's 32 windows of 1 000)
 #endif
 #ifndef RK_WINDOW_MIN_BRANCHES
 #define RK_WINDOW_MIN_BRANCHES 1116u  // up to here the dense 16-lane geometry keeps eight waves per CU; beyond it the windowed kernel is ahead (scripts/tree_size_sweep.py: 1 300 branches 241 against 219 Mreads/s, 2 800: 185 against 141)
@@ -235,17 +235,23 @@ struct rk_workspace {
 };
 
 // mid-size trees: the score vector of a read is held one window of W branches at a time (place_packed16w_kernel)
+constexpr uint32_t RK_MAX_WINDOWS = 32;  // 5-bit window ids in winspec and in the item tags
+// winspec byte of a row that reaches the windows first .. last: first | span << 5, span 7 = "at least seven more: to the last window"
+static inline unsigned char winspec_byte(uint32_t first, uint32_t last) {
+    const uint32_t span = last - first;
+    return (unsigned char)(first | ((span < 7u ? span : 7u) << 5));
+}
 struct WindowPlan {
     uint32_t W = 0, n_win = 0, s_stride = 0, main_cap = 0, work_cap = 0;
 };
 
 // The dense 16-lane geometry keeps eight waves per CU up to 1 116 branches (choose_geometry); beyond that -- and up to the
-// 16 000 branches slot-offset images are built for -- the tree is cut into windows of <= 1 000 branches, at most 16 of them
-// (4-bit window ids in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
+// 32 000 branches slot-offset images are built for -- the tree is cut into windows of <= 1 000 branches, at most 32 of them
+// (5-bit window ids in winspec and in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
 static bool window_plan(uint32_t nb, WindowPlan &wp) {
     if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
     uint32_t n_win = (nb + 895) / 896;
-    if (n_win > 16) n_win = 16;
+    if (n_win > RK_MAX_WINDOWS) n_win = RK_MAX_WINDOWS;
     wp.n_win = n_win;
     wp.W = ((nb + n_win - 1) / n_win + 3) & ~3u;
     wp.s_stride = wp.W + 4;
@@ -546,7 +552,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     std::vector<uint64_t> desc(n_keys);  // by key number
     WindowPlan wp;
     const bool want_windows = !indexed && window_plan(d->n_branches, wp);
-    std::vector<unsigned char> ws_by_key;  // first window | (last - first) << 4 of every row
+    std::vector<unsigned char> ws_by_key;  // winspec_byte(first window, last window) of every row
     if (want_windows) {
         try { ws_by_key.assign(n_keys, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
     }
@@ -606,7 +612,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
                     ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
                     ep[i].score = v;
                 }
-                if (want_windows) ws_by_key[r] = (unsigned char)((xmin / wp.W) | ((xmax / wp.W - xmin / wp.W) << 4));
+                if (want_windows) ws_by_key[r] = winspec_byte(xmin / wp.W, xmax / wp.W);
                 if (indexed) {
                     std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
                     unsigned char *row = (unsigned char *)(blob.data() + (desc[r] >> DESC_LEN_BITS));
@@ -1009,7 +1015,13 @@ static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipS
 static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_per_read) {
     static const bool off = getenv("RK_NO_WINDOW") != nullptr;  // developer knob: A/B against the dense kernels
     // (scripts/keep_at_most_sweep.py, windowed against dense, Mreads/s: 3 999 branches K = 9 / 12 / 16: 156 / 141 / 105 against 91 / 84 / 76)
-    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && words_per_read <= 16;
+    // Records of more than 16 words (the kernel then reads its k-mers from memory, and a long read is emitted in several window
+    // ranges): ahead of the dense kernels while a read has fewer symbols than about a ninth of the tree's branches
+    // (scripts/read_length_sweep.py, G k-mers/s windowed against dense: 3 999 branches 300 / 450 / 600 bp: 25.6 / 19.8 / 16.4 against
+    // 18.3 / 20.6 / 22.0; 7 999: 450 / 600 / 1000 bp: 17.5 / 15.2 / 10.8 against 11.8 / 12.7 / 14.4; 15 999: 1000 bp 9.7 against 6.8)
+    const uint64_t max_symbols = (uint64_t)words_per_read * 32 / db->info.bits_per_symbol;
+    const bool fits = words_per_read <= 16 || max_symbols * 9 <= db->info.n_branches || db->info.n_branches > 16000;  // (25 001 branches: 10.2 against 3.3 at 1000 bp)
+    return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && fits;
 }
 
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {

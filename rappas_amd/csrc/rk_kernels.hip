@@ -1381,7 +1381,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // (94 Mreads/s at 3 999 branches against 340 at 999).  Here S holds one WINDOW of win_w branches at a time, so a read costs the
 // LDS of a 1 000-branch tree whatever the tree's size:
 //   probe + emit once: every 128-byte row unit becomes one item of the read's MAIN list, in k-mer order, tagged with the span
-//     of windows its row touches (winspec, one byte per k-mer next to the compact table: first window | (last - first) << 4);
+//     of windows its row touches (winspec, one byte per k-mer next to the compact table: first window | min(last - first, 7) << 5, 7 = to the last window);
 //   for every window: the items whose span contains it are compacted (order kept) into a WORK list and applied by
 //     accumulate_units with a window filter on the slot offsets (entries of other windows fall on the scratch word); then the
 //     usual select over the window, whose K best are merged into the K best so far.
@@ -1413,7 +1413,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
     const int main_usable = (int)a.main_cap;
     const int work_usable = (int)a.work_cap - 3 * U - 2;
     const int cap_rows = (int)(a.work_cap / 2) - 1;
-    const u32 wpr = a.words_per_read;  // <= 16
+    const u32 wpr = a.words_per_read;  // (beyond 16 words the k-mers are read from memory: fetch_batch)
 
     for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
     wave_lds_fence();
@@ -1442,8 +1442,17 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
         return (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
     };
+    const u32 *c_rec = a.packed;  // the current tile's record in memory (records of more than 16 words do not fit one word per lane)
     auto fetch_batch = [&](u32 recw, u32 pos, u32 Q, u64 (&code)[PU], RawSlot (&raw)[PU], u32 (&wsr)[PU]) {
-        record_codes<BITS, PU>(recw, pos, li, k, Q, code);
+        if (wpr <= 16) {
+            record_codes<BITS, PU>(recw, pos, li, k, Q, code);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const u32 j = pos + (u32)u * G + li;
+                code[u] = extract_code<BITS>(c_rec, wpr, j < Q ? j : 0u, k);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < PU; u++) {
             raw[u] = lookup_fetch<BITS, TM>(a.db, code[u]);
@@ -1482,6 +1491,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         const u64 r = tile * NG + gi;
         const bool have = c_have;
+        c_rec = a.packed + (have ? r : 0ull) * wpr;
         const u32 fin = c_fin;
         u32 R = c_R;
         {
@@ -1497,16 +1507,19 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         RK_STAMP(0);  // tile setup
 
         // ---- emit: every row unit of the read whose row reaches a window of [wa, wb) -> one tagged item of the main list, k-mer
-        //      order.  Called with all windows first; if some read of the tile does not fit its main list the window range is cut
-        //      in two and each half emitted on its own (a row's items count in every half its span reaches); a half that still
-        //      does not fit takes the per-window probe of window_accumulate ----
+        //      order.  Called with all windows first; if some read of the tile does not fit its main list, the window range is cut
+        //      into 2, 4, ... ranges (as many as the largest read's unit count asks for) and each range emitted on its own (a
+        //      row's items count in every range its span reaches); a range that still does not fit takes the per-window probe of
+        //      window_accumulate ----
         int mcnt = 0;
         bool overflow = false;  // wave-uniform: some read of the tile does not fit its main list
         u32 touched = 0;        // windows some row of this lane's k-mers reaches (bit w), from the first call
+        u32 all_items = 0;      // row units of this lane's k-mers over the whole tree (the first emit counts them even when it overflows)
         auto emit_range = [&](u32 wa, u32 wb) {
             mcnt = 0;
             overflow = false;
-            const u32 range = (1u << wb) - (1u << wa);
+            all_items = 0;
+            const u32 range = (wb >= 32u ? 0u : (1u << wb)) - (1u << wa);
             for (u32 pos = 0; __any(pos < Q); pos += PU * G) {
                 u64 code[PU], desc[PU];
                 RawSlot raw[PU];
@@ -1518,12 +1531,13 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 int total = 0;
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
-                    const u32 f = ws[u] & 15u, l0 = f + (ws[u] >> 4), l = l0 < 15u ? l0 : 15u;
-                    const u32 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (2u << l) - (1u << f) : 0u;
+                    const u32 f = ws[u] & 31u, sp = ws[u] >> 5, l0 = sp == 7u ? 31u : f + sp, l = l0 < 31u ? l0 : 31u;
+                    const u32 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (2u << l) - (1u << f) : 0u;  // bits f..l (l = 31: 2u << 31 wraps to 0)
                     touched |= span;
                     nch[u] = (span & range) ? (((u32)desc[u] & DESC_LEN_MASK) + G - 1) >> 4 : 0u;  // <= 255 units (compact table)
+                    all_items += nch[u];
                 }
-                if (overflow) continue;  // (the rest of the read is probed for its spans alone)
+                if (overflow) continue;  // (the rest of the read is probed for its spans and its size alone)
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
                     const u32 incl = row_scan(nch[u]);
@@ -1533,8 +1547,8 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 if (__any(pos < Q && mcnt + total > main_usable)) { overflow = true; continue; }
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
-                    const u32 sp = ws[u] >> 4;
-                    const u32 tag = (ws[u] & 15u) | ((sp < 7u ? sp : 7u) << 4);
+                    const u32 sp = ws[u] >> 5;
+                    const u32 tag = (ws[u] & 31u) | ((sp < 3u ? sp : 3u) << 5);  // item tag: first window | span << 5, span 3 = to the last window
                     const u32 rb = (u32)(desc[u] >> DESC_LEN_BITS) * 8u;
                     const int base = mcnt + (int)excl[u];
                     if (nch[u] > 0) mainl[base] = rb | tag;
@@ -1548,8 +1562,8 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         };
         u32 n_recw = 0, n_R = 0, n_fin = 0;  // next tile's inputs: loaded after the first emit, in flight during the window passes
         bool n_have = false;
-        u32 tile_windows = 0xFFFFu;
-        bool split = false;  // wave-uniform: the tile did not fit whole, its windows run in two halves
+        u32 tile_windows = 0xFFFFFFFFu;
+        u32 parts = 1;  // wave-uniform: a tile that does not fit its main list whole runs its windows in 2, 4, ... ranges, one emit each
 
         // this window's entries of the read applied to S (window w holds the branches [w * W, w * W + win_n))
         auto window_accumulate = [&](u32 w) {
@@ -1583,9 +1597,9 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     const int i = base + (int)li;
                     const u32 it = nxt;
                     nxt = mainl[i + G];
-                    const u32 sp = (it >> 4) & 7u;
-                    const u32 span = ((sp + 1u) & 8u) | sp;  // tag 7 = "to the last window"
-                    const bool sel = (w - (it & 15u)) <= span && i < mcnt;  // unsigned: w below the first window wraps
+                    const u32 sp = (it >> 5) & 3u;
+                    const u32 span = sp == 3u ? 31u : sp;  // tag 3 = "to the last window"
+                    const bool sel = (w - (it & 31u)) <= span && i < mcnt;  // unsigned: w below the first window wraps
                     const u64 mg = __ballot(sel) & gmask_mine;
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((u32)(mg >> 32), __builtin_amdgcn_mbcnt_lo((u32)mg, 0u));
                     if (__any(wc + G > work_usable)) flushw();
@@ -1613,7 +1627,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     decode_batch(code, raw, pos, Q, desc);
 #pragma unroll
                     for (int u = 0; u < PU; u++) {
-                        const u32 f = ws[u] & 15u, l = f + (ws[u] >> 4);
+                        const u32 f = ws[u] & 31u, l = (ws[u] >> 5) == 7u ? 31u : f + (ws[u] >> 5);
                         const bool hit = ((u32)desc[u] & DESC_LEN_MASK) != 0 && f <= w && w <= l;
                         if (__any(rc + G > cap_rows)) flush_rows();
                         const u64 sub = (__ballot(hit) >> (gi * G)) & gmask;
@@ -1628,7 +1642,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         // reset; the K rounds run once, over the whole tree.  Phase 1, only if an entry a stream had to drop could still belong to
         // the answer (a stream would need >= 3 of the K best): the tile again, with the exact select of every window and a merge of
         // the windows' K best.  Windows no read of the tile reaches are skipped whole (their S is in its reset state): reads of one
-        // clade fill one or two of up to sixteen windows.  (One loop over phases and halves so that the emit, the window pass and
+        // clade fill one or two of up to 32 windows.  (One loop over phases and halves so that the emit, the window pass and
         // the two selects exist once in the code: the copies an unrolled structure makes cost registers.)
         u64 acc_key = 0;  // lane r < K: rank-r key (low 16 bits: 0xFFFF - tree branch id)
         bool doubt = false;
@@ -1640,11 +1654,10 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 if (!__any(doubt)) break;
                 acc_key = 0;
             }
-            for (u32 part = 0; part < (split ? 2u : 1u); part++) {
-                const u32 h = NWIN / 2;
-                const u32 wa = (split && part) ? h : 0u, wb = (split && !part) ? h : NWIN;
-                if (split && !((tile_windows >> wa) & ((1u << (wb - wa)) - 1u))) continue;  // nothing in this half
-                if (first || split) emit_range(wa, wb);  // (the exact pass of an unsplit tile finds its main list as the fast pass left it)
+            for (u32 part = 0; part < parts; part++) {
+                const u32 wa = part * NWIN / parts, wb = (part + 1) * NWIN / parts;
+                if (parts > 1 && !((tile_windows >> wa) & ((1u << (wb - wa)) - 1u))) continue;  // nothing in this range (or an empty one)
+                if (first || parts > 1) emit_range(wa, wb);  // (the exact pass of an unsplit tile finds its main list as the fast pass left it)
                 if (first) {
                     first = false;
                     u32 t = touched | row_ror32<8>(touched);
@@ -1652,11 +1665,19 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     t |= row_ror32<2>(t);
                     t |= row_ror32<1>(t);
                     tile_windows = __builtin_amdgcn_readlane(t, 0) | __builtin_amdgcn_readlane(t, 16) | __builtin_amdgcn_readlane(t, 32) | __builtin_amdgcn_readlane(t, 48);
-                    if (RK_ABLATE & 4096) tile_windows = 0xFFFFu;
+                    if (RK_ABLATE & 4096) tile_windows = 0xFFFFFFFFu;
                     load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
                     RK_STAMP(1);  // probe + emit
-                    if (overflow) {  // the whole tree does not fit: start over, in halves (part becomes 0 again)
-                        split = true;
+                    if (overflow) {  // the whole tree does not fit: start over in as many ranges as the largest read needs (part becomes 0 again)
+                        u32 n = all_items + row_ror32<8>(all_items);
+                        n += row_ror32<4>(n);
+                        n += row_ror32<2>(n);
+                        n += row_ror32<1>(n);
+                        const u32 most = max(max((u32)__builtin_amdgcn_readlane((int)n, 0), (u32)__builtin_amdgcn_readlane((int)n, 16)),
+                                             max((u32)__builtin_amdgcn_readlane((int)n, 32), (u32)__builtin_amdgcn_readlane((int)n, 48)));
+                        parts = 2;
+                        while (parts < NWIN && most > parts * (u32)main_usable * 7u / 8u) parts *= 2;  // (a row that spans ranges counts in each: headroom)
+                        if (parts > NWIN) parts = NWIN;
                         part = ~0u;
                         continue;
                     }

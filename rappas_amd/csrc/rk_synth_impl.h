@@ -157,7 +157,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
 
     WindowPlan wp;
     const bool want_windows = window_plan(d->n_branches, wp);  // (used only when the image turns out not to be an indexed one)
-    std::vector<unsigned char> winspec;  // [space] first window | (last - first) << 4 of every row (rows are branch runs)
+    std::vector<unsigned char> winspec;  // [space] winspec_byte(first, last window) of every row (rows are branch runs)
     if (want_windows) {
         try { winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create_synth: host OOM"); }
     }
@@ -181,7 +181,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
                         lpart[t].push_back(len);
                         if (want_windows) {
                             const u32 b0 = synth_b0(sp, h0, len), f = b0 / wp.W, l = (b0 + len - 1) / wp.W;
-                            winspec[c] = (unsigned char)(f | ((l - f) << 4));
+                            winspec[c] = winspec_byte(f, l);
                         }
                     }
                 } catch (const std::bad_alloc &) { oom = true; }

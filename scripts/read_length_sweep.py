@@ -6,7 +6,7 @@ import rappas_amd as ra
 from rappas_amd import synth
 
 lengths = [int(x) for x in sys.argv[1:]] or [100, 150, 250, 256, 300, 450, 600]
-for nb in (999, 3999):
+for nb in [int(x) for x in os.environ.get("RK_SWEEP_BRANCHES", "999,3999").split(",")]:
     sdb = synth.make_db(4, 10, nb, 786432, 10_000_000, seed=42)
     db = ra.PhyloKmerDB.from_synth(sdb)
     pp = ra.PlacementProcess(db)

@@ -732,6 +732,23 @@ def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, 
         assert st["placed"] == len(lens)
 
 
+@pytest.mark.parametrize("n_branches,length", [(7999, 420), (7999, 700), (20001, 300), (31999, 150), (31999, 1200), (3999, 330)])
+def test_windowed_kernel_long_records_and_up_to_32_windows(n_branches, length):
+    """records of more than 16 words (k-mers read from memory), reads emitted in several window ranges, 5-bit window ids"""
+    sdb = synth.make_db(4, 8, n_branches, 50000, 650000, seed=n_branches + length)
+    odb = O.OracleDB.from_synth(sdb)
+    seq, off = synth.make_reads(4, 500, length, seed=length, amb_rate=0.0005, bad_rate=0.002, var_len=length // 2)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_packed16w_kernel" in db.kernel_name(), db.kernel_name()
+    db.close()
+    for K in (7, 12):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K)
+        assert st["placed"] > 400
+    sc = _scatter_rows(synth.make_db(4, 7, n_branches, 12000, 150000, seed=length), seed=n_branches)  # rows over all windows: span tags "to the last"
+    seq, off = synth.make_reads(4, 300, min(length, 400), seed=3)
+    run_case(sc, O.OracleDB.from_synth(sc), seq, off, "direct", 0, "mean")
+
+
 def test_windowed_kernel_protein_and_keep_at_most():
     sdb = synth.make_db(20, 3, 3100, 6000, 60000, seed=6)
     odb = O.OracleDB.from_synth(sdb)
