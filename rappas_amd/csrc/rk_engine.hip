@@ -36,6 +36,9 @@ using namespace rk;
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
 #endif
+#ifndef RK_WG_RING
+#define RK_WG_RING RK_RING  // the same for the large-tree kernel
+#endif
 #ifndef RK_WRING
 #define RK_WRING RK_RING  // the same for the windowed kernel
 #endif
@@ -1136,7 +1139,7 @@ static int launch_wg_v(const rk_db *db, const WgGeometry &g, PlaceArgs a, hipStr
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * g.nw), g.lds, stream, a);
         return RK_OK;
     };
-    if (int rc = db->info.rows_bytes < ROWS_FIT32_LIMIT ? launch(place_wg_kernel<BITS, TM, false, RK_RING>) : launch(place_wg_kernel<BITS, TM, true, RK_RING>)) return rc;
+    if (int rc = db->info.rows_bytes < ROWS_FIT32_LIMIT ? launch(place_wg_kernel<BITS, TM, false, RK_WG_RING>) : launch(place_wg_kernel<BITS, TM, true, RK_WG_RING>)) return rc;
     HIP_TRY(hipGetLastError());
     return RK_OK;
 }
