@@ -37,7 +37,9 @@ using namespace rk;
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
 #endif
 #ifndef RK_WG_RING
-#define RK_WG_RING RK_RING  // the same for the large-tree kernel
+#define RK_WG_RING 20  // the same for the large-tree kernel, whose waves stream long row slices from HBM: what counts there is bytes in flight
+                       // (C5s: rings of 8 / 12 / 16 / 20 / 24 / 32 give 0.72 / 0.76 / 0.77 / 0.79 / 0.78 / 0.77 of the byte roofline;
+                       // C5 at 200 GB 0.61 -> 0.65, C5m 0.60 -> 0.63; short-row trees beyond 32 000 branches lose 7 %)
 #endif
 #ifndef RK_WRING
 #define RK_WRING RK_RING  // the same for the windowed kernel
@@ -1229,7 +1231,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         if (choose_wg_geometry(db, wg) != RK_OK) return "";
         snprintf(buf, sizeof(buf), "place_wg_kernel<BITS=%u,%s,%s,U=%d> waves/WG=%u lds/WG=%zuB rows/batch=%u WGs/CU=%u passes=%u",
                  db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_HASH ? "HASH" : "DIRECT8",
-                 db->info.rows_bytes < ROWS_FIT32_LIMIT ? "OFF32" : "OFF64", RK_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu, wg.n_pass);
+                 db->info.rows_bytes < ROWS_FIT32_LIMIT ? "OFF32" : "OFF64", RK_WG_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu, wg.n_pass);
         m->kernel_name = buf;
         return m->kernel_name.c_str();
     }
