@@ -246,6 +246,14 @@ static inline unsigned char winspec_byte(uint32_t first, uint32_t last) {
     const uint32_t span = last - first;
     return (unsigned char)(first | ((span < 7u ? span : 7u) << 5));
 }
+// The windowed kernel holds a read's row units in a list of a few hundred items: beyond ~2.2 units per k-mer code (a 150-bp read
+// then brings ~300) a read is emitted in many window ranges and the dense kernels are ahead (scripts/row_length_sweep.py, 3 999
+// branches, mean row 100 / 250 entries: 113 / 35 against 87 / 49 Mreads/s) -- unless the tree is so large that they hold one read
+// per CU (beyond 16 000 branches)
+static inline bool windows_pay(uint32_t nb, uint64_t blob_units, uint64_t space) {
+    if (getenv("RK_WINDOW_ALWAYS")) return true;  // developer / test knob: the windowed kernel whatever the row density
+    return 5 * blob_units <= 11 * space || nb > 16000;
+}
 struct WindowPlan {
     uint32_t W = 0, n_win = 0, s_stride = 0, main_cap = 0, work_cap = 0;
 };
@@ -678,7 +686,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     img.blob_bytes = blob_bytes;
     img.max_len = max_len;
     // windows need the compact table (rows of <= 255 units) and 32-bit row offsets
-    if (want_windows && img.mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT) {
+    if (want_windows && img.mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT && windows_pay(d->n_branches, blob_units, space)) {
         try { img.winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
         for (uint64_t i = 0; i < n_keys; i++) img.winspec[order[i].first] = ws_by_key[order[i].second];
         img.windowed = true;

@@ -261,7 +261,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     SY_TRY(hipMalloc(&db->d_rows, blob_bytes));
     if (table_bytes) SY_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
     SY_TRY(hipMemset(db->d_rows, indexed ? 0xFF : 0, unit_bytes));  // unit 0: the reserved "skip" / scratch pattern
-    if (want_windows && !indexed && mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT) {
+    if (want_windows && !indexed && mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT && windows_pay(d->n_branches, blob_units, space)) {
         SY_TRY(hipMalloc((void **)&db->d_winspec, winspec.size()));
         SY_TRY(hipMemcpy(db->d_winspec, winspec.data(), winspec.size(), hipMemcpyHostToDevice));
         db->windowed = true;

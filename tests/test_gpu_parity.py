@@ -703,9 +703,11 @@ def test_windowed_kernel_rows_scattered_over_all_windows():
     assert st["placed"] == 1500
 
 
-def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window():
+def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window(monkeypatch):
     """250-bp reads against a database where every k-mer has a row of ~40 entries: ~700 row units per read, more than the main
-    list holds -> the per-window probe with the row cursor"""
+    list holds -> window ranges and the per-window probe with the row cursor (rows this dense normally take the dense kernels:
+    RK_WINDOW_ALWAYS keeps the windowed image)"""
+    monkeypatch.setenv("RK_WINDOW_ALWAYS", "1")
     sdb = synth.make_db(4, 6, 6001, 4096, 160000, seed=4)
     seq, off = synth.make_reads(4, 1200, 250, seed=8, var_len=120)
     _, _, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, "mean")
@@ -713,10 +715,11 @@ def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window()
 
 
 @pytest.mark.parametrize("n_branches,mean_row", [(7999, 26), (3999, 30), (15999, 18)])
-def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, mean_row):
+def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, mean_row, monkeypatch):
     """every k-mer hits a row of two units on average: ~300 row units per 150-bp read, more than the main list holds for the whole
     tree but not for half of its windows -> the tile is emitted once per half; mixed with short reads (fit whole) and 250-bp reads
     (do not fit a half either: the per-window probe)"""
+    monkeypatch.setenv("RK_WINDOW_ALWAYS", "1")  # (rows this dense normally take the dense kernels)
     sdb = synth.make_db(4, 7, n_branches, 16384, 16384 * mean_row, seed=n_branches)
     odb = O.OracleDB.from_synth(sdb)
     parts = [synth.make_reads(4, 900, 150, seed=21), synth.make_reads(4, 300, 60, seed=22, var_len=30), synth.make_reads(4, 150, 250, seed=23)]
@@ -747,6 +750,16 @@ def test_windowed_kernel_long_records_and_up_to_32_windows(n_branches, length):
     sc = _scatter_rows(synth.make_db(4, 7, n_branches, 12000, 150000, seed=length), seed=n_branches)  # rows over all windows: span tags "to the last"
     seq, off = synth.make_reads(4, 300, min(length, 400), seed=3)
     run_case(sc, O.OracleDB.from_synth(sc), seq, off, "direct", 0, "mean")
+
+
+def test_dense_rows_on_a_mid_size_tree_take_the_dense_kernels():
+    """beyond ~2.2 row units per k-mer code a read's units no longer fit the windowed kernel's lists (scripts/row_length_sweep.py)"""
+    sdb = synth.make_db(4, 6, 5001, 4096, 4096 * 60, seed=2)  # every k-mer present, rows of ~60 entries: ~4 units per code
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_packed16w_kernel" not in db.kernel_name(), db.kernel_name()
+    db.close()
+    seq, off = synth.make_reads(4, 800, 150, seed=12, var_len=50)
+    run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, "mean")
 
 
 def test_windowed_kernel_protein_and_keep_at_most():
