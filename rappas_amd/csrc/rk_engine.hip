@@ -249,10 +249,11 @@ static inline unsigned char winspec_byte(uint32_t first, uint32_t last) {
 // The windowed kernel holds a read's row units in a list of a few hundred items: beyond ~2.2 units per k-mer code (a 150-bp read
 // then brings ~300) a read is emitted in many window ranges and the dense kernels are ahead (scripts/row_length_sweep.py, 3 999
 // branches, mean row 100 / 250 entries: 113 / 35 against 87 / 49 Mreads/s) -- unless the tree is so large that they hold one read
-// per CU (beyond 16 000 branches)
+// in two or three waves per CU (beyond 8 192 branches; scripts/dense_rows_mid_tree.py, every k-mer present with rows of 30 / 60
+// entries: 9 001 branches 66 / 45 against 41 / 36, 15 999: 49 / 36 against 17 / 15; longer rows there take the large-tree image)
 static inline bool windows_pay(uint32_t nb, uint64_t blob_units, uint64_t space) {
     if (getenv("RK_WINDOW_ALWAYS")) return true;  // developer / test knob: the windowed kernel whatever the row density
-    return 5 * blob_units <= 11 * space || nb > 16000;
+    return 5 * blob_units <= 11 * space || nb > RK_WG_MIN_BRANCHES;
 }
 struct WindowPlan {
     uint32_t W = 0, n_win = 0, s_stride = 0, main_cap = 0, work_cap = 0;
