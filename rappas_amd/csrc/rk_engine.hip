@@ -27,7 +27,10 @@ using namespace rk;
 #define RK_WG_MIN_BRANCHES 8192u  // above this a single-wave score vector leaves <= 4 waves per CU: use place_wg_kernel
 #endif
 #ifndef RK_WG_MIN_MEAN_ROW
-#define RK_WG_MIN_MEAN_ROW 64.0     // ... for rows at least this long on average ...
+#define RK_WG_MIN_MEAN_ROW 320.0    // ... for rows at least this long on average (scripts/long_rows_big_tree.py: up to ~300 entries the windowed kernel is ahead:
+                                    // 15 999 branches, mean row 70 / 150 / 300: 54 / 36 / 19 against 22 / 19 / 17 Mreads/s) ...
+#endif
+#ifndef RK_WG_ALWAYS_BRANCHES
 #define RK_WG_ALWAYS_BRANCHES 32000u  // ... or, whatever the rows, above this many branches (the windowed kernel's 32 windows of 1 000)
 #endif
 #ifndef RK_WINDOW_MIN_BRANCHES

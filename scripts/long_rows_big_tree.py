@@ -1,0 +1,24 @@
+"""Developer measurement: large-tree (workgroup-per-read) image against the windowed one on trees of 9 001 ... 25 001 branches, by row length.
+RK_LIB=<variant built with -DRK_WG_MIN_MEAN_ROW=1e9> keeps the rows out of the large-tree image."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rappas_amd as ra
+from rappas_amd import synth
+n = 300_000
+for nb in (9001, 15999, 25001):
+    for mean in [int(x) for x in sys.argv[1:]] or [70, 150, 400, 1000]:
+        keys = 65536
+        sdb = synth.make_db(4, 9, nb, keys, keys * mean, seed=42)  # a quarter of the k-mers present
+        db = ra.PhyloKmerDB.from_synth(sdb)
+        pp = ra.PlacementProcess(db)
+        wpr = db.packed_words(150)
+        packed = torch.randint(-2**31, 2**31, (n, wpr), dtype=torch.int64, device="cuda").to(torch.int32)
+        packed[:, wpr - 1] &= (1 << (300 - 32 * (wpr - 1))) - 1
+        out = pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(3):
+            pp.place_packed(packed, fixed_len=150, out=out)
+        torch.cuda.synchronize()
+        print(f"n_branches={nb:6d} mean row {mean:5d}: {n / ((time.time() - t) / 3) / 1e6:7.1f} Mreads/s   [{db.kernel_name()[:44]}]", flush=True)
+        db.close()

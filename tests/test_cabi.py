@@ -109,7 +109,7 @@ def test_db_validate_builds_image_without_device():
     assert h.table_mode == _lib.RK_TABLE_HASH and h.table_slots >= 2 * sdb.n_keys and h.table_bytes == h.table_slots * 16
     aa = synth.make_db(20, 3, 30, 500, 2000, seed=1)
     assert _validate(aa).bits_per_symbol == 5
-    big = synth.make_db(4, 6, 19999, 300, 60000, seed=2)     # large tree: indexed rows (+1 line per row), 8-byte descriptors
+    big = synth.make_db(4, 6, 19999, 300, 150000, seed=2)    # large tree, long rows: indexed rows (+1 line per row), 8-byte descriptors
     bi = _validate(big)
     bl = np.diff(big.row_offsets.astype(np.int64))
     # [index line][u16 branch[lenp]][f32 score[lenp]] with lenp padded to 32 entries: 6 bytes per entry
