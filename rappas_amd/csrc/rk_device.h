@@ -52,7 +52,7 @@ struct DbView {
     u32 mono;  // every score >= T (all increments >= 0): first touch of a branch can be a max with the -inf marker
     u32 soa;  // large-tree (indexed) images: a row is u16 branch[len] followed by f32 score[len] (6 bytes per entry)
     // mid-size trees (place_packed16w_kernel): the tree is cut into n_win windows of win_w branches; winspec[dense k-mer index] =
-    // (first window its row touches, 5 bits) | min(last - first, 7) << 5 (7 = to the last window), 0 for absent k-mers; nullptr when
+    // (first window its row touches, 6 bits) | min(last - first, 3) << 6 (3 = to the last window), 0 for absent k-mers; nullptr when
     // the image is not windowed
     const unsigned char *winspec;
     u32 win_w, n_win;

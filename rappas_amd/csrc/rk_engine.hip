@@ -31,7 +31,7 @@ using namespace rk;
                                     // 15 999 branches, mean row 70 / 150 / 300: 54 / 36 / 19 against 22 / 19 / 17 Mreads/s) ...
 #endif
 #ifndef RK_WG_ALWAYS_BRANCHES
-#define RK_WG_ALWAYS_BRANCHES 32000u  // ... or, whatever the rows, above this many branches (the windowed kernel's 32 windows of 1 000)
+#define RK_WG_ALWAYS_BRANCHES 65535u  // ... or, whatever the rows, above this many branches (none: the windowed kernel's 64 windows of 1 024 cover every tree)
 #endif
 #ifndef RK_WINDOW_MIN_BRANCHES
 #define RK_WINDOW_MIN_BRANCHES 1116u  // up to here the dense 16-lane geometry keeps eight waves per CU; beyond it the windowed kernel is ahead (scripts/tree_size_sweep.py: 1 300 branches 241 against 219 Mreads/s, 2 800: 185 against 141)
@@ -243,12 +243,13 @@ struct rk_workspace {
 };
 
 // mid-size trees: the score vector of a read is held one window of W branches at a time (place_packed16w_kernel)
-constexpr uint32_t RK_MAX_WINDOWS = 32;  // 5-bit window ids in winspec and in the item tags
-// winspec byte of a row that reaches the windows first .. last: first | span << 5, span 7 = "at least seven more: to the last window"
+constexpr uint32_t RK_MAX_WINDOWS = 64;  // 6-bit window ids in winspec and in the item tags
+// winspec byte of a row that reaches the windows first .. last: first | span << 6, span 3 = "at least three more: to the last window"
 static inline unsigned char winspec_byte(uint32_t first, uint32_t last) {
     const uint32_t span = last - first;
-    return (unsigned char)(first | ((span < 7u ? span : 7u) << 5));
+    return (unsigned char)(first | ((span < 3u ? span : 3u) << 6));
 }
+constexpr uint64_t RK_WINDOW_MAX_BLOB = 1ull << 31;  // list items carry a 24-bit index of 128-byte units
 // The windowed kernel holds a read's row units in a list of a few hundred items: beyond ~2.2 units per k-mer code (a 150-bp read
 // then brings ~300) a read is emitted in many window ranges and the dense kernels are ahead (scripts/row_length_sweep.py, 3 999
 // branches, mean row 100 / 250 entries: 113 / 35 against 87 / 49 Mreads/s) -- unless the tree is so large that they hold one read
@@ -263,8 +264,8 @@ struct WindowPlan {
 };
 
 // The dense 16-lane geometry keeps eight waves per CU up to 1 116 branches (choose_geometry); beyond that -- and up to the
-// 32 000 branches slot-offset images are built for -- the tree is cut into windows of <= 1 000 branches, at most 32 of them
-// (5-bit window ids in winspec and in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
+// 65 535 branches of the reference -- the tree is cut into windows of <= 1 024 branches, at most 64 of them
+// (6-bit window ids in winspec and in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
 static bool window_plan(uint32_t nb, WindowPlan &wp) {
     if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
     uint32_t n_win = (nb + 895) / 896;
@@ -283,6 +284,24 @@ static bool window_plan(uint32_t nb, WindowPlan &wp) {
     wp.work_cap = work & ~1u;
     wp.main_cap = (avail - wp.work_cap) & ~1u;
     return wp.main_cap >= 160;
+}
+
+// Which image a database gets, from its row lengths alone (slot_units = sum of ceil(len / 16) + 1, max_len, mean_len):
+//   windowed (slot-offset rows + winspec, place_packed16w_kernel) when window_plan has a plan, the compact table applies (DIRECT or
+//     AUTO over a small enough key space, no row beyond 255 units), the blob stays below 2 GB and windows_pay says so;
+//   large-tree (indexed rows, place_wg_kernel) beyond 8 192 branches when the rows are long (mean >= RK_WG_MIN_MEAN_ROW), or when
+//     no windowed image is possible beyond 16 000 branches (there the dense kernels hold one read per CU, or none at all beyond
+//     ~39 000);
+//   the plain slot-offset image of the dense kernels otherwise.
+struct ImageKind { bool indexed, windowable; };
+static ImageKind image_kind(uint32_t nb, uint32_t table_mode, uint64_t space, bool space_ok, uint64_t slot_units, uint32_t max_len, double mean_len) {
+    WindowPlan wp;
+    const bool direct = table_mode == RK_TABLE_DIRECT || (table_mode == RK_TABLE_AUTO && space_ok && space <= (1ull << 28));
+    const bool windowable = window_plan(nb, wp) && direct && (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB &&
+                            windows_pay(nb, slot_units, space);
+    const bool long_rows = mean_len >= RK_WG_MIN_MEAN_ROW;
+    const bool indexed = nb > RK_WG_MIN_BRANCHES && (long_rows || (!windowable && nb > 16000u));
+    return {indexed, windowable && !indexed};
 }
 
 struct rk_db {
@@ -564,11 +583,19 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     // a few resident score vectors does better (measured, rows of ~13 entries: 12 001 branches 29 vs 20 Mreads/s; the
     // workgroup kernel is ahead again from ~16 000 branches on, where two score vectors fill a CU, and always for long rows).
     const double mean_len = n_keys ? (double)n_entries / (double)n_keys : 0.0;
-    const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES && (mean_len >= RK_WG_MIN_MEAN_ROW || d->n_branches > RK_WG_ALWAYS_BRANCHES);
+    uint64_t slot_units = 1;
+    uint32_t longest = 0;
+    for (uint64_t r = 0; r < n_keys; r++) {
+        const uint64_t len = d->row_offsets[r + 1] - d->row_offsets[r];
+        slot_units += (len + ROW_UNIT - 1) / ROW_UNIT;
+        if (len > longest) longest = (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len);
+    }
+    const ImageKind kind = image_kind(d->n_branches, d->table_mode, space, space_ok, slot_units, longest, mean_len);
+    const bool indexed = kind.indexed;
     img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
     WindowPlan wp;
-    const bool want_windows = !indexed && window_plan(d->n_branches, wp);
+    const bool want_windows = kind.windowable && window_plan(d->n_branches, wp);
     std::vector<unsigned char> ws_by_key;  // winspec_byte(first window, last window) of every row
     if (want_windows) {
         try { ws_by_key.assign(n_keys, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
@@ -690,7 +717,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     img.blob_bytes = blob_bytes;
     img.max_len = max_len;
     // windows need the compact table (rows of <= 255 units) and 32-bit row offsets
-    if (want_windows && img.mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT && windows_pay(d->n_branches, blob_units, space)) {
+    if (want_windows && img.mode == RK_TABLE_DIRECT && blob_bytes < RK_WINDOW_MAX_BLOB) {
         try { img.winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
         for (uint64_t i = 0; i < n_keys; i++) img.winspec[order[i].first] = ws_by_key[order[i].second];
         img.windowed = true;
@@ -1130,6 +1157,7 @@ static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
 }
 
 static int check_launchable(const rk_db *db) {
+    if (db->windowed) return RK_OK;  // (the windowed and the ambiguity kernel hold windows of any tree; a forced dense geometry is checked at launch)
     if (db->indexed) {
         WgGeometry wg;
         return choose_wg_geometry(db, wg);
@@ -1185,7 +1213,6 @@ static int launch_ascii_v(const rk_db *db, PlaceArgs args, AmbArgs m, hipStream_
             if (chunk > args.s_stride) chunk = args.s_stride;
         }
     } else {
-        if (!db->indexed) return fail(RK_ERR_UNSUPPORTED, "internal: a slot-offset image with n_branches=%u", nb);
         // 12 bytes per branch of the window (S + Samb + Camb): the window is as large as one CU allows, split evenly
         const size_t per = (db->lds_per_cu - list_bytes - 64) / 12;
         uint32_t n_win = (uint32_t)((nb + per - 1) / per);
@@ -1306,9 +1333,10 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
     if (!d_lens && (uint64_t)fixed_len * db->info.bits_per_symbol > (uint64_t)words_per_read * 32)
         return fail(RK_ERR_INVALID, "rk_place_packed_device: fixed_len=%u does not fit %u words", fixed_len, words_per_read);
     const bool use_wg = db->indexed && db->lanes_per_read == 0;  // an explicit lanes_per_read forces the single-wave kernel
+    const bool use_win = !use_wg && use_windowed(db, p->keep_at_most, words_per_read);
     Geometry g{};
     WgGeometry wg{};
-    rc = use_wg ? choose_wg_geometry(db, wg) : choose_geometry(db, p->keep_at_most, g);
+    rc = use_wg ? choose_wg_geometry(db, wg) : (use_win ? RK_OK : choose_geometry(db, p->keep_at_most, g));  // (the windowed launch has its own plan)
     if (rc) return rc;
     HIP_TRY(hipSetDevice(db->info.device));
     hipStream_t s = (hipStream_t)stream;
@@ -1324,7 +1352,7 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
     a.s_stride = use_wg ? wg.s_stride : g.s_stride;
     a.list_cap = use_wg ? wg.list_cap : g.list_cap;
     if (use_wg) rc = launch_wg(db, wg, a, s);
-    else if (use_windowed(db, p->keep_at_most, words_per_read)) rc = launch_windowed(db, a, s);
+    else if (use_win) rc = launch_windowed(db, a, s);
     else rc = launch_place(db, g, a, s);
     if (rc) return rc;
     if (ascii) {

@@ -1381,7 +1381,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // (94 Mreads/s at 3 999 branches against 340 at 999).  Here S holds one WINDOW of win_w branches at a time, so a read costs the
 // LDS of a 1 000-branch tree whatever the tree's size:
 //   probe + emit once: every 128-byte row unit becomes one item of the read's MAIN list, in k-mer order, tagged with the span
-//     of windows its row touches (winspec, one byte per k-mer next to the compact table: first window | min(last - first, 7) << 5, 7 = to the last window);
+//     of windows its row touches (winspec, one byte per k-mer next to the compact table: first window | min(last - first, 3) << 6, 3 = to the last window);
 //   for every window: the items whose span contains it are compacted (order kept) into a WORK list and applied by
 //     accumulate_units with a window filter on the slot offsets (entries of other windows fall on the scratch word); then the
 //     usual select over the window, whose K best are merged into the K best so far.
@@ -1513,13 +1513,13 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         //      window_accumulate ----
         int mcnt = 0;
         bool overflow = false;  // wave-uniform: some read of the tile does not fit its main list
-        u32 touched = 0;        // windows some row of this lane's k-mers reaches (bit w), from the first call
+        u64 touched = 0;        // windows some row of this lane's k-mers reaches (bit w), from the first call
         u32 all_items = 0;      // row units of this lane's k-mers over the whole tree (the first emit counts them even when it overflows)
         auto emit_range = [&](u32 wa, u32 wb) {
             mcnt = 0;
             overflow = false;
             all_items = 0;
-            const u32 range = (wb >= 32u ? 0u : (1u << wb)) - (1u << wa);
+            const u64 range = (wb >= 64u ? 0ull : (1ull << wb)) - (1ull << wa);
             for (u32 pos = 0; __any(pos < Q); pos += PU * G) {
                 u64 code[PU], desc[PU];
                 RawSlot raw[PU];
@@ -1531,8 +1531,8 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 int total = 0;
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
-                    const u32 f = ws[u] & 31u, sp = ws[u] >> 5, l0 = sp == 7u ? 31u : f + sp, l = l0 < 31u ? l0 : 31u;
-                    const u32 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (2u << l) - (1u << f) : 0u;  // bits f..l (l = 31: 2u << 31 wraps to 0)
+                    const u32 f = ws[u] & 63u, sp = ws[u] >> 6, l0 = sp == 3u ? 63u : f + sp, l = l0 < 63u ? l0 : 63u;
+                    const u64 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (2ull << l) - (1ull << f) : 0ull;  // bits f..l (l = 63: 2 << 63 wraps to 0)
                     touched |= span;
                     nch[u] = (span & range) ? (((u32)desc[u] & DESC_LEN_MASK) + G - 1) >> 4 : 0u;  // <= 255 units (compact table)
                     all_items += nch[u];
@@ -1547,14 +1547,13 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                 if (__any(pos < Q && mcnt + total > main_usable)) { overflow = true; continue; }
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
-                    const u32 sp = ws[u] >> 5;
-                    const u32 tag = (ws[u] & 31u) | ((sp < 3u ? sp : 3u) << 5);  // item tag: first window | span << 5, span 3 = to the last window
-                    const u32 rb = (u32)(desc[u] >> DESC_LEN_BITS) * 8u;
+                    // item: 128-byte unit index << 8 | the row's winspec byte (first window | span << 6, span 3 = to the last window)
+                    const u32 unit = (u32)(desc[u] >> DESC_LEN_BITS) >> 4, tag = ws[u];
                     const int base = mcnt + (int)excl[u];
-                    if (nch[u] > 0) mainl[base] = rb | tag;
-                    if (nch[u] > 1) mainl[base + 1] = (rb + 128u) | tag;
+                    if (nch[u] > 0) mainl[base] = (unit << 8) | tag;
+                    if (nch[u] > 1) mainl[base + 1] = ((unit + 1u) << 8) | tag;
                     for (u32 c = 2; __any(c < nch[u]); c++)
-                        if (c < nch[u]) mainl[base + (int)c] = (rb + c * 128u) | tag;
+                        if (c < nch[u]) mainl[base + (int)c] = ((unit + c) << 8) | tag;
                 }
                 mcnt += total;
             }
@@ -1562,7 +1561,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         };
         u32 n_recw = 0, n_R = 0, n_fin = 0;  // next tile's inputs: loaded after the first emit, in flight during the window passes
         bool n_have = false;
-        u32 tile_windows = 0xFFFFFFFFu;
+        u64 tile_windows = ~0ull;
         u32 parts = 1;  // wave-uniform: a tile that does not fit its main list whole runs its windows in 2, 4, ... ranges, one emit each
 
         // this window's entries of the read applied to S (window w holds the branches [w * W, w * W + win_n))
@@ -1597,13 +1596,13 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     const int i = base + (int)li;
                     const u32 it = nxt;
                     nxt = mainl[i + G];
-                    const u32 sp = (it >> 5) & 3u;
-                    const u32 span = sp == 3u ? 31u : sp;  // tag 3 = "to the last window"
-                    const bool sel = (w - (it & 31u)) <= span && i < mcnt;  // unsigned: w below the first window wraps
+                    const u32 sp = (it >> 6) & 3u;
+                    const u32 span = sp == 3u ? 63u : sp;  // tag 3 = "to the last window"
+                    const bool sel = (w - (it & 63u)) <= span && i < mcnt;  // unsigned: w below the first window wraps
                     const u64 mg = __ballot(sel) & gmask_mine;
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((u32)(mg >> 32), __builtin_amdgcn_mbcnt_lo((u32)mg, 0u));
                     if (__any(wc + G > work_usable)) flushw();
-                    if (sel) work[wc + rank] = it & ~127u;
+                    if (sel) work[wc + rank] = (it >> 8) << 7;  // unit index -> byte offset of the unit
                     wc += __builtin_popcount((u32)mg) + __builtin_popcount((u32)(mg >> 32));
                 }
                 if (__any(wc > 0)) flushw();
@@ -1627,7 +1626,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     decode_batch(code, raw, pos, Q, desc);
 #pragma unroll
                     for (int u = 0; u < PU; u++) {
-                        const u32 f = ws[u] & 31u, l = (ws[u] >> 5) == 7u ? 31u : f + (ws[u] >> 5);
+                        const u32 f = ws[u] & 63u, l = (ws[u] >> 6) == 3u ? 63u : f + (ws[u] >> 6);
                         const bool hit = ((u32)desc[u] & DESC_LEN_MASK) != 0 && f <= w && w <= l;
                         if (__any(rc + G > cap_rows)) flush_rows();
                         const u64 sub = (__ballot(hit) >> (gi * G)) & gmask;
@@ -1642,7 +1641,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         // reset; the K rounds run once, over the whole tree.  Phase 1, only if an entry a stream had to drop could still belong to
         // the answer (a stream would need >= 3 of the K best): the tile again, with the exact select of every window and a merge of
         // the windows' K best.  Windows no read of the tile reaches are skipped whole (their S is in its reset state): reads of one
-        // clade fill one or two of up to 32 windows.  (One loop over phases and halves so that the emit, the window pass and
+        // clade fill one or two of up to 64 windows.  (One loop over phases and halves so that the emit, the window pass and
         // the two selects exist once in the code: the copies an unrolled structure makes cost registers.)
         u64 acc_key = 0;  // lane r < K: rank-r key (low 16 bits: 0xFFFF - tree branch id)
         bool doubt = false;
@@ -1656,16 +1655,19 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
             }
             for (u32 part = 0; part < parts; part++) {
                 const u32 wa = part * NWIN / parts, wb = (part + 1) * NWIN / parts;
-                if (parts > 1 && !((tile_windows >> wa) & ((1u << (wb - wa)) - 1u))) continue;  // nothing in this range (or an empty one)
+                if (parts > 1 && !((tile_windows >> wa) & ((1ull << (wb - wa)) - 1ull))) continue;  // nothing in this range (or an empty one)
                 if (first || parts > 1) emit_range(wa, wb);  // (the exact pass of an unsplit tile finds its main list as the fast pass left it)
                 if (first) {
                     first = false;
-                    u32 t = touched | row_ror32<8>(touched);
-                    t |= row_ror32<4>(t);
-                    t |= row_ror32<2>(t);
-                    t |= row_ror32<1>(t);
-                    tile_windows = __builtin_amdgcn_readlane(t, 0) | __builtin_amdgcn_readlane(t, 16) | __builtin_amdgcn_readlane(t, 32) | __builtin_amdgcn_readlane(t, 48);
-                    if (RK_ABLATE & 4096) tile_windows = 0xFFFFFFFFu;
+                    auto group_or = [&](u32 t) -> u32 {
+                        t |= row_ror32<8>(t);
+                        t |= row_ror32<4>(t);
+                        t |= row_ror32<2>(t);
+                        t |= row_ror32<1>(t);
+                        return (u32)(__builtin_amdgcn_readlane((int)t, 0) | __builtin_amdgcn_readlane((int)t, 16) | __builtin_amdgcn_readlane((int)t, 32) | __builtin_amdgcn_readlane((int)t, 48));
+                    };
+                    tile_windows = ((u64)group_or((u32)(touched >> 32)) << 32) | group_or((u32)touched);
+                    if (RK_ABLATE & 4096) tile_windows = ~0ull;
                     load_tile(tile + wave_count, n_recw, n_R, n_fin, n_have);
                     RK_STAMP(1);  // probe + emit
                     if (overflow) {  // the whole tree does not fit: start over in as many ranges as the largest read needs (part becomes 0 again)
@@ -1683,7 +1685,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
                     }
                 }
                 for (u32 w = wa; w < wb; w++) {
-                    if (!((tile_windows >> w) & 1u)) continue;
+                    if (!((tile_windows >> w) & 1ull)) continue;
                     window_accumulate(w);
                     const u32 wlo = w * W;
                     const u32 win_n = nb - wlo < W ? nb - wlo : W;
@@ -2280,7 +2282,8 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         if (!SOA && fit32 && !any_long && !(RK_ABLATE & 256)) {
                             // the usual case: every pending row is one chunk -> the buffer-addressed unit path of the packed kernel
                             // (descriptors turned into unit items in place: every lane first reads its <= 3 descriptors)
-                            // (slot-offset images are only built for trees that fit the LDS whole: s_lo == 0 here)
+                            // (slot-offset images of trees beyond the LDS -- the windowed kernel's, up to 65 535 branches -- carry tree-wide
+                            // slot offsets: the window filter of accumulate_units rebases them and sends the rest to the scratch word)
                             u64 dreg[3];
 #pragma unroll
                             for (int t = 0; t < 3; t++) dreg[t] = ((int)lane + 64 * t < cnt) ? clist[lane + 64 * t] : 0ull;
@@ -2292,7 +2295,10 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                                     items[lane + 64 * t] = ((u32)(dreg[t] >> DESC_LEN_BITS) * 8u) | ((((u32)dreg[t] & DESC_LEN_MASK) >> 4) - 1u);
                             for (int i = cnt + (int)lane; i < cnt + 2 * RK_ASCII_RING; i += 64) items[i] = ITEM_FILLER;
                             wave_lds_fence();
-                            if (a.db.mono) accumulate_units<64, RK_ASCII_RING, true>(S, items, cnt, lane, rows_rs, QT, T);
+                            if (n_win > 1) {
+                                if (a.db.mono) accumulate_units<64, RK_ASCII_RING, true, true>(S, items, cnt, lane, rows_rs, QT, T, s_lo * 4u + 4u, nb * 4u);
+                                else accumulate_units<64, RK_ASCII_RING, false, true>(S, items, cnt, lane, rows_rs, QT, T, s_lo * 4u + 4u, nb * 4u);
+                            } else if (a.db.mono) accumulate_units<64, RK_ASCII_RING, true>(S, items, cnt, lane, rows_rs, QT, T);
                             else accumulate_units<64, RK_ASCII_RING, false>(S, items, cnt, lane, rows_rs, QT, T);
                             wave_lds_fence();
                             cnt = 0;
@@ -2300,7 +2306,10 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         }
                         if (lane == 0) clist[cnt] = 0;  // sentinel: an empty row ends the cursor
                         wave_lds_fence();
-                        if (!(RK_ABLATE & 256)) accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T, s_lo, SOA ? nb : 0xFFFFu);
+                        if (!(RK_ABLATE & 256)) {
+                            if (!SOA && n_win > 1) accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T, s_lo, 0xFFFFu, s_lo * 4u + 4u, nb * 4u);
+                            else accumulate_list<64, RK_ASCII_RING, true, SOA>(S, nb, clist, cnt, lane, a.db.rows, QT, T, s_lo, SOA ? nb : 0xFFFFu);
+                        }
                         wave_lds_fence();
                         cnt = 0;
                         any_long = false;

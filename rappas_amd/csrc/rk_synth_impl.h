@@ -204,7 +204,10 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     uint32_t max_len = 0;
     for (uint64_t i = 0; i < n_keys; i++) { n_entries += lens32[i]; if (lens32[i] > max_len) max_len = (uint32_t)lens32[i]; }
     const double mean_len = n_keys ? (double)n_entries / (double)n_keys : 0.0;
-    const bool indexed = d->n_branches > RK_WG_MIN_BRANCHES && (mean_len >= RK_WG_MIN_MEAN_ROW || d->n_branches > RK_WG_ALWAYS_BRANCHES);
+    uint64_t slot_units = 1;
+    for (uint64_t i = 0; i < n_keys; i++) slot_units += (lens32[i] + ROW_UNIT - 1) / ROW_UNIT;
+    const ImageKind kind = image_kind(d->n_branches, d->table_mode, space, true, slot_units, max_len, mean_len);
+    const bool indexed = kind.indexed;
     const uint64_t unit_bytes = indexed ? 64 : ROW_UNIT * 8;
     uint64_t blob_units = 1, max_units = 0;
     std::vector<u64> &desc = lens32;  // lengths become descriptors in place
@@ -261,7 +264,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     SY_TRY(hipMalloc(&db->d_rows, blob_bytes));
     if (table_bytes) SY_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
     SY_TRY(hipMemset(db->d_rows, indexed ? 0xFF : 0, unit_bytes));  // unit 0: the reserved "skip" / scratch pattern
-    if (want_windows && !indexed && mode == RK_TABLE_DIRECT && blob_bytes < ROWS_FIT32_LIMIT && windows_pay(d->n_branches, blob_units, space)) {
+    if (want_windows && kind.windowable && mode == RK_TABLE_DIRECT && blob_bytes < RK_WINDOW_MAX_BLOB) {
         SY_TRY(hipMalloc((void **)&db->d_winspec, winspec.size()));
         SY_TRY(hipMemcpy(db->d_winspec, winspec.data(), winspec.size(), hipMemcpyHostToDevice));
         db->windowed = true;

@@ -485,9 +485,14 @@ def test_tree_at_the_reference_limit(mean_row, amb):
     seq, off = synth.make_reads(4, 300, 150, seed=3, amb_rate=0.004, var_len=40)
     got, ref, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct8", 0, amb)
     assert st["placed"] > 250
-    db = ra.PhyloKmerDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb, table_mode=ra.RK_TABLE_DIRECT8)
     assert "passes=2" in db.kernel_name()
     db.close()
+    if mean_row == 12:  # short rows with the compact table: the windowed kernel's 64 windows of 1 024 branches
+        db = ra.PhyloKmerDB.from_synth(sdb)
+        assert "windows=64 x 1024" in db.kernel_name(), db.kernel_name()
+        db.close()
+        run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, amb)
 
 
 @pytest.mark.parametrize("n_branches", [39001, 50000])
@@ -678,7 +683,7 @@ def _clade_db(k, n_branches, genome_len, seed, mean_row=12.0, jitter=5):
     return synth.SynthDB(4, k, n_branches, thr, thr_log10, key_codes, off, branch, scores, seed), "".join("ATCG"[int(b)] for b in g)
 
 
-@pytest.mark.parametrize("n_branches", [999, 3999, 9001, 20001])
+@pytest.mark.parametrize("n_branches", [999, 3999, 9001, 20001, 65535])
 @pytest.mark.parametrize("K", [3, 7, 8])
 def test_best_branches_that_are_neighbours(n_branches, K):
     """the K best branches of every read are adjacent ids: the stream heads of the fast select must keep them apart (and the exact
@@ -735,9 +740,11 @@ def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, 
         assert st["placed"] == len(lens)
 
 
-@pytest.mark.parametrize("n_branches,length", [(7999, 420), (7999, 700), (20001, 300), (31999, 150), (31999, 1200), (3999, 330)])
-def test_windowed_kernel_long_records_and_up_to_32_windows(n_branches, length):
-    """records of more than 16 words (k-mers read from memory), reads emitted in several window ranges, 5-bit window ids"""
+@pytest.mark.parametrize("n_branches,length", [(7999, 420), (7999, 700), (20001, 300), (31999, 150), (31999, 1200), (3999, 330),
+                                               (40001, 150), (65535, 150), (65535, 500)])
+def test_windowed_kernel_long_records_and_up_to_64_windows(n_branches, length):
+    """records of more than 16 words (k-mers read from memory), reads emitted in several window ranges, 6-bit window ids: every
+    tree the reference accepts (65 534 branch ids) as long as its rows are short"""
     sdb = synth.make_db(4, 8, n_branches, 50000, 650000, seed=n_branches + length)
     odb = O.OracleDB.from_synth(sdb)
     seq, off = synth.make_reads(4, 500, length, seed=length, amb_rate=0.0005, bad_rate=0.002, var_len=length // 2)
