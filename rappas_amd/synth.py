@@ -18,6 +18,12 @@ CONFIGS = {
     "C1": (4, 8, 50, 49_152, 500_000, 150, 1_000),
     "C2": (4, 10, 500, 786_432, 10_000_000, 150, 10_000_000),
     "C4": (20, 5, 200, 320_000, 3_200_000, 100, 1_000_000),
+    # not BASELINE configs: C2's database and reads on larger reference trees (bench.py --config T4k / T8k / T20k / T64k; the
+    # tree-size curve of scripts/tree_size_sweep.py as bench lines)
+    "T4k": (4, 10, 2_000, 786_432, 10_000_000, 150, 4_000_000),
+    "T8k": (4, 10, 4_000, 786_432, 10_000_000, 150, 4_000_000),
+    "T20k": (4, 10, 10_000, 786_432, 10_000_000, 150, 2_000_000),
+    "T64k": (4, 10, 32_768, 786_432, 10_000_000, 150, 2_000_000),
     "C5mini": (4, 12, 10_000, 1_048_576, 50_000_000, 250, 100_000),  # C5's tree/k at a DB size one test can hold
     # C5-shaped per-read work (19 999 branches, rows of ~2 600 entries, 250 bp => H ~ 4.7e5 entries/read) with a smaller
     # key space (k=8) so that the DB is ~1 GB instead of 200 GB: beyond the Infinity Cache, i.e. HBM-bound like C5
