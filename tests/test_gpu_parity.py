@@ -760,6 +760,20 @@ def test_windowed_kernel_long_records_and_up_to_64_windows(n_branches, length):
     run_case(sc, O.OracleDB.from_synth(sc), seq, off, "direct", 0, "mean")
 
 
+@pytest.mark.parametrize("n_branches", [20001, 65535])
+def test_windowed_kernel_protein_on_large_trees(n_branches):
+    """5-bit records, up to 64 windows, reads beyond 16 record words (103+ residues), ambiguity classes B / Z / J / X"""
+    sdb = synth.make_db(20, 3, n_branches, 7000, 80000, seed=n_branches)
+    odb = O.OracleDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_packed16w_kernel<BITS=5" in db.kernel_name(), db.kernel_name()
+    db.close()
+    for length in (90, 240):
+        seq, off = synth.make_reads(20, 700, length, seed=length, amb_rate=0.002, bad_rate=0.002, var_len=length // 2)
+        for K in (7, 16):
+            run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K)
+
+
 def test_dense_rows_on_a_mid_size_tree_take_the_dense_kernels():
     """beyond ~2.2 row units per k-mer code a read's units no longer fit the windowed kernel's lists (scripts/row_length_sweep.py)"""
     sdb = synth.make_db(4, 6, 5001, 4096, 4096 * 60, seed=2)  # every k-mer present, rows of ~60 entries: ~4 units per code
