@@ -447,7 +447,8 @@ static int build_table(uint32_t &mode, uint64_t space, uint64_t n_keys, bool ind
     static const bool bytes_only = getenv("RK_COMPACT_BYTES") != nullptr;  // developer knob: A/B against the byte form
     // ... where rows stream at all: with fewer than one row unit per two k-mer codes (C4: 0.13) the probes outnumber the row lines,
     // nothing evicts the table and the longer decode is all that is left (C4: 5.37e8 against 5.52e8 reads/s)
-    nib = mode == RK_TABLE_DIRECT && max_units <= 15 && 2 * blob_units >= space && !bytes_only;
+    static const bool nibbles_always = getenv("RK_COMPACT_NIBBLES") != nullptr;  // developer knob: the half-size form whatever the density
+    nib = mode == RK_TABLE_DIRECT && max_units <= 15 && (2 * blob_units >= space || nibbles_always) && !bytes_only;
     try {
         if (mode == RK_TABLE_DIRECT) {
             slots = space;

@@ -133,6 +133,20 @@ __device__ __forceinline__ u64 extract_code(const u32 *rec, u32 words, u32 j, u3
 template <int BITS>
 __device__ __forceinline__ u64 dense_index(u64 code, u32 k) {
     if (BITS == 2) return code;
+    if (k <= 7) {
+        // direct tables exist for 20^k <= 2^31, i.e. k <= 7: digits 0..5 sit in the low word, digit 6 straddles it, digits at and
+        // above k are zero -- Horner from the top in 32-bit arithmetic, two instructions a digit (the general loop below is 64-bit
+        // shifts and multiplies with a run-time trip count: ~10 x the work, paid twice per probe)
+        const u32 lo = (u32)code;
+        u32 idx = (u32)(code >> 30) & 31u;
+        idx = idx * 20u + ((lo >> 25) & 31u);
+        idx = idx * 20u + ((lo >> 20) & 31u);
+        idx = idx * 20u + ((lo >> 15) & 31u);
+        idx = idx * 20u + ((lo >> 10) & 31u);
+        idx = idx * 20u + ((lo >> 5) & 31u);
+        idx = idx * 20u + (lo & 31u);
+        return idx;
+    }
     u64 idx = 0, pw = 1;
     for (u32 i = 0; i < k; i++) {
         idx += ((code >> (5 * i)) & 31) * pw;

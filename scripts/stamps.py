@@ -15,16 +15,23 @@ os.environ["RK_LIB"] = so
 import numpy as np, torch
 import rappas_amd as ra
 from rappas_amd import synth
-sdb = synth.make_db(4, 10, branches, 786432, 10_000_000, seed=42) if branches else synth.make_config_db("C2")
+cfg = next((a.split("=")[1] for a in extra if a.startswith("--config=")), "C2")  # C2 or C4
+sdb = synth.make_db(4, 10, branches, 786432, 10_000_000, seed=42) if branches else synth.make_config_db(cfg)
+rlen = synth.CONFIGS[cfg][5] if not branches else 150
+bits = 2 if sdb.alphabet == 4 else 5
 mode = {"auto": ra.RK_TABLE_AUTO, "direct": ra.RK_TABLE_DIRECT, "direct8": ra.RK_TABLE_DIRECT8, "hash": ra.RK_TABLE_HASH}[table]
 db = ra.PhyloKmerDB.from_synth(sdb, table_mode=mode)
 pp = ra.PlacementProcess(db)
 n = 4_000_000
-wpr = db.packed_words(150)
-packed = torch.randint(-2**31, 2**31, (n, wpr), dtype=torch.int64, device="cuda").to(torch.int32)
-packed[:, wpr - 1] &= (1 << (300 - 32 * (wpr - 1))) - 1
-pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
-pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
+if bits == 2:
+    wpr = db.packed_words(rlen)
+    packed = torch.randint(-2**31, 2**31, (n, wpr), dtype=torch.int64, device="cuda").to(torch.int32)
+    packed[:, wpr - 1] &= (1 << (2 * rlen - 32 * (wpr - 1))) - 1
+else:  # amino acids: digits must stay below 20 -- pack real reads on the device
+    seq, off = synth.make_reads(20, n, rlen, seed=1)
+    packed, _, _ = pp.pack_reads(torch.from_numpy(seq).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), rlen)
+pp.place_packed(packed, fixed_len=rlen); torch.cuda.synchronize()
+pp.place_packed(packed, fixed_len=rlen); torch.cuda.synchronize()
 lib = ra._lib.load()
 nw = 2048
 buf = (C.c_ulonglong * (nw * 16))()
