@@ -166,11 +166,11 @@ template <int BITS, int TM>
 __device__ __forceinline__ RawSlot lookup_fetch(const DbView &db, u64 code) {
     RawSlot r;
     if (TM == TM_COMPACT) {
-        const u64 idx = dense_index<BITS>(code, db.k);
-        const u32 blk = (u32)(idx / COMPACT_KMERS);
+        const u32 idx = (u32)dense_index<BITS>(code, db.k);  // (direct tables: sigma^k <= 2^31 -- 32-bit division by a constant, not 64-bit)
+        const u32 blk = idx / COMPACT_KMERS;
         r.v = db.compact[db.compact_nib ? blk >> 1 : blk];
     } else {  // TM_DIRECT8
-        const uint2 d = *(const uint2 *)(db.direct + dense_index<BITS>(code, db.k));
+        const uint2 d = *(const uint2 *)(db.direct + (u32)dense_index<BITS>(code, db.k));
         r.v = make_uint4(d.x, d.y, 0u, 0u);
     }
     return r;
@@ -181,13 +181,13 @@ __device__ __forceinline__ u64 lookup_decode(const DbView &db, const RawSlot &r,
     if (TM == TM_COMPACT) {
         // 16-byte block of COMPACT_KMERS (12) consecutive k-mers: {u32 first 128-byte unit of the block's rows,
         // 12 x u8 units per row}; the row offset is the block base plus a byte prefix sum (v_sad_u8 accumulates)
-        const u64 idx = dense_index<BITS>(code, db.k);
-        const u32 i = (u32)(idx % COMPACT_KMERS);
+        const u32 idx = (u32)dense_index<BITS>(code, db.k);
+        const u32 i = idx % COMPACT_KMERS;
         const uint4 n = r.v;
         if (db.compact_nib) {
             // the half-size form (no row of the database exceeds 15 units): {u32 first unit, 24 x u4 units per row}; k-mer i of the
             // odd 12-block sits in the block's second half.  Nibble sums: even and odd nibbles through v_sad_u8 each.
-            const u32 j = i + ((u32)(idx / COMPACT_KMERS) & 1u) * COMPACT_KMERS;
+            const u32 j = i + ((idx / COMPACT_KMERS) & 1u) * COMPACT_KMERS;
             auto nsum = [](u32 w, u32 acc) {
                 return __builtin_amdgcn_sad_u8(w & 0x0F0F0F0Fu, 0u, __builtin_amdgcn_sad_u8((w >> 4) & 0x0F0F0F0Fu, 0u, acc));
             };
@@ -1470,7 +1470,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
 #pragma unroll
         for (int u = 0; u < PU; u++) {
             raw[u] = lookup_fetch<BITS, TM>(a.db, code[u]);
-            wsr[u] = a.db.winspec[dense_index<BITS>(code[u], k)];
+            wsr[u] = a.db.winspec[(u32)dense_index<BITS>(code[u], k)];
         }
     };
     auto decode_batch = [&](const u64 (&code)[PU], const RawSlot (&raw)[PU], u32 pos, u32 Q, u64 (&desc)[PU]) {
