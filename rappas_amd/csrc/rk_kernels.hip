@@ -1149,8 +1149,13 @@ __device__ __forceinline__ void record_codes(u32 recw, u32 pos, u32 li, u32 k, u
         const u32 w0 = __shfl(recw, (int)(wi & 15u), 16);
         u32 w1 = __shfl(recw, (int)((wi + 1) & 15u), 16);
         w1 = wi + 1 < 16 ? w1 : 0u;
-        u64 c = (((u64)w1 << 32) | w0) >> sh;
         const u32 nbits = k * BITS;
+        if (nbits <= 32) {  // (uniform) the code fits one word: a funnel shift over two record words, no third word, no 64-bit shifts
+            const u32 c32 = __builtin_amdgcn_alignbit(w1, w0, sh);
+            code[u] = nbits == 32 ? c32 : (c32 & ((1u << nbits) - 1u));
+            continue;
+        }
+        u64 c = (((u64)w1 << 32) | w0) >> sh;
         if (BITS * 12 + 31 > 64) {
             u32 w2 = __shfl(recw, (int)((wi + 2) & 15u), 16);
             w2 = (wi + 2 < 16 && nbits + sh > 64) ? w2 : 0u;
