@@ -38,8 +38,14 @@ def parse():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (host buffers through rk_place_batch / rk_place_batch_packed)")
     ap.add_argument("--pcie-reads", type=int, default=4_000_000, help="reads of the PCIe-inclusive leg (rank 0, N=1)")
     ap.add_argument("--db-scale", type=float, default=1.0)
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to rehearse the multi-rank path on one GPU")
+    ap.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "gloo", "none"],
+                    help="how ranks do the barriers / max-over-ranks (there is no collective on the data path): auto = nccl (RCCL), "
+                         "falling back to none if RCCL cannot be set up; gloo = CPU tensors (rehearsals); none = no process group, "
+                         "file rendezvous + CLOCK_MONOTONIC stamps (one node)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher / rank bookkeeping rehearsal WITHOUT a GPU: no engine, no placement, a step is a 5 ms sleep; "
+                         "the JSON line says so and carries no rate (tests of --gpus N on CPU)")
     a = ap.parse_args()
     long_cfg = {"C3": 10, "C5": 3, "C5s": 10, "C5m": 5, "C5mini": 20, "T4k": 40, "T8k": 30, "T20k": 30, "T64k": 20}
     if a.steps <= 0:
@@ -112,30 +118,305 @@ def count_entries_torch(torch, table, sigma, k, bits, packed, length, chunk=1 <<
     return total, hits
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Rank bookkeeping.  The data path has no collective (reads are independent: PlacementProcess.java:1067-1075),
+# so the only cross-rank steps are the two barriers around the timed region, the MAX over ranks of the elapsed
+# time and the collection of per-rank rates.  Three ways to do them:
+#   nccl  = RCCL through torch.distributed (what the driver's torch.distributed.run launch gets by default),
+#   gloo  = the same calls on CPU tensors (rehearsals on one GPU / without a GPU),
+#   none  = no process group at all: ranks rendezvous through files in a directory private to the job and
+#           stamp start / end with CLOCK_MONOTONIC (system-wide on Linux, all ranks are on ONE node); the
+#           job's elapsed time is max(end) - min(start), which is >= every rank's own bracketed time.
+#   auto  = nccl, and if its set-up raises on any rank every rank falls back to `none` (a vote through the
+#           same directory, so all ranks take the same branch).
+# Whatever the backend, every rank leaves `result.<rank>.json` in the job directory and rank 0 folds the
+# per-rank rates into the one JSON line.
+# ---------------------------------------------------------------------------------------------------------
+EX_PG_FAILED = 75  # a rank that could not set up its process group exits with this (EX_TEMPFAIL)
+
+
+def job_dir():
+    """Directory shared by the ranks of ONE job on this node.  The self-launcher creates it and passes it down;
+    under torch.distributed.run every worker is a child of the same agent process, so (agent pid, MASTER_PORT)
+    names the job."""
+    d = os.environ.get("RK_BENCH_JOB_DIR")
+    if not d:
+        import tempfile
+        d = os.path.join(tempfile.gettempdir(), f"rk_bench_{os.getuid()}_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _put(path, text):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)  # atomic: a reader sees the whole file or none of it
+
+
+class RankSync:
+    """barrier / max-over-ranks / per-rank results for bench.py (see the block comment above)."""
+
+    def __init__(self, rank, world, backend, device=None, timeout_s=600.0):
+        self.rank, self.world, self.device, self.timeout_s = rank, world, device, timeout_s
+        self.dir = job_dir() if world > 1 else None
+        self.backend = backend if world > 1 else "single"
+        self.note = None
+        self._n = 0
+        self.dist = None
+        if world == 1:
+            return
+        if backend in ("nccl", "gloo", "auto"):
+            err = self._init_pg("nccl" if backend == "auto" else backend)
+            if backend == "auto":
+                # all ranks take the same branch: nccl only if it came up on every one of them
+                _put(os.path.join(self.dir, f"pg.{rank}"), "ok" if err is None else f"failed: {err}")
+                votes = self._wait_all("pg", read=True)
+                bad = {r: v for r, v in votes.items() if v != "ok"}
+                if bad:
+                    if err is None:
+                        self._destroy_pg()
+                    r0 = min(bad)
+                    self.backend, self.note = "none", f"nccl set-up failed on rank(s) {sorted(bad)} ({bad[r0][:200]}); fell back to --dist-backend none"
+                    if rank == 0:
+                        print("bench.py: " + self.note, file=sys.stderr, flush=True)
+                else:
+                    self.backend = "nccl"
+            elif err is not None:
+                _put(os.path.join(self.dir, f"pg_failed.{rank}"), err)
+                print(f"bench.py: rank {rank}: {backend} process group failed: {err}", file=sys.stderr, flush=True)
+                raise SystemExit(EX_PG_FAILED)
+        _put(os.path.join(self.dir, f"pg_done.{rank}"), self.backend)
+
+    # -- torch.distributed -------------------------------------------------------------------------------
+    def _init_pg(self, backend):
+        try:
+            import datetime
+            import torch
+            import torch.distributed as dist
+            kw = dict(timeout=datetime.timedelta(seconds=float(os.environ.get("RK_BENCH_PG_TIMEOUT", "180"))))
+            if os.environ.get("RK_BENCH_INIT_FILE"):  # self-launched ranks rendezvous through a file: no port to race for
+                kw.update(init_method="file://" + os.environ["RK_BENCH_INIT_FILE"], rank=self.rank, world_size=self.world)
+            else:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                if self.device is None:
+                    raise RuntimeError("nccl needs a GPU per rank")
+                dist.init_process_group("nccl", device_id=self.device, **kw)
+            else:
+                dist.init_process_group("gloo", **kw)
+            self.dist = dist
+            if dist.get_world_size() != self.world:
+                raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus says {self.world}")
+            # one real collective now, so that a broken transport shows here and not inside the timed region
+            t = torch.ones(1, dtype=torch.float64, device=self.device if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            if int(t.item()) != self.world:
+                raise RuntimeError(f"all_reduce over {self.world} ranks returned {t.item()}")
+            return None
+        except Exception as e:  # noqa: BLE001 -- reported, then either a fallback (auto) or a non-zero exit
+            self._destroy_pg()
+            return f"{type(e).__name__}: {e}"
+
+    def _destroy_pg(self):
+        try:
+            if self.dist is not None and self.dist.is_initialized():
+                self.dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        self.dist = None
+
+    # -- files -------------------------------------------------------------------------------------------
+    def _wait_all(self, stem, read=False, ranks=None):
+        """wait until `<stem>.<r>` exists for every rank; RuntimeError naming the missing ranks after timeout_s"""
+        ranks = list(range(self.world)) if ranks is None else ranks
+        t_end = time.monotonic() + self.timeout_s
+        missing = ranks
+        while True:
+            missing = [r for r in missing if not os.path.exists(os.path.join(self.dir, f"{stem}.{r}"))]
+            if not missing:
+                break
+            if time.monotonic() > t_end:
+                raise RuntimeError(f"bench.py: rank {self.rank} waited {self.timeout_s:.0f} s at '{stem}' for rank(s) {missing}")
+            time.sleep(0.0005)
+        if not read:
+            return None
+        return {r: open(os.path.join(self.dir, f"{stem}.{r}")).read() for r in ranks}
+
+    def barrier(self):
+        if self.world == 1:
+            return
+        if self.backend in ("nccl", "gloo"):
+            self.dist.barrier()
+            return
+        self._n += 1
+        _put(os.path.join(self.dir, f"barrier{self._n}.{self.rank}"), "")
+        self._wait_all(f"barrier{self._n}")
+
+    def finish(self, t_start, t_end, mine):
+        """every rank: publish its own record; rank 0: (whole-job elapsed seconds, list of per-rank records)"""
+        elapsed = t_end - t_start
+        if self.world == 1:
+            return elapsed, [mine]
+        if self.backend in ("nccl", "gloo"):
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        _put(os.path.join(self.dir, f"result.{self.rank}"), json.dumps(dict(mine, rank=self.rank, t_start=t_start, t_end=t_end, pid=os.getpid())))
+        if self.rank != 0:
+            return elapsed, None
+        recs = [json.loads(v) for _, v in sorted(self._wait_all("result", read=True).items())]
+        if self.backend == "none":
+            elapsed = max(r["t_end"] for r in recs) - min(r["t_start"] for r in recs)
+        return elapsed, recs
+
+    def close(self):
+        if self.world == 1:
+            return
+        if self.backend in ("nccl", "gloo"):
+            try:
+                self.dist.barrier()
+            finally:
+                self._destroy_pg()
+        _put(os.path.join(self.dir, f"closed.{self.rank}"), "")
+        if self.rank == 0 and not os.environ.get("RK_BENCH_JOB_DIR"):  # under a launcher the job directory is ours to remove
+            import shutil
+            self._wait_all("closed")
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one fresh process per GPU).
 
-    Runs before torch is imported or any HIP call is made in this process; the parent never touches the GPU, it only
-    waits, forwards rank 0's JSON line and fails if any rank failed.  Children get RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT exactly as `torch.distributed.run` would set them."""
-    import socket
+    Runs before torch is imported or any HIP call is made in this process: the parent never touches the GPU.  It
+    polls its children; when one exits non-zero it stops the others within seconds and exits non-zero with that
+    rank's stderr tail (rank 0 would otherwise sit in the rendezvous until its timeout).  If the ranks die, or
+    hang, while setting up the nccl / gloo process group, a fresh set is started with `--dist-backend none`.
+    Children get RANK / LOCAL_RANK / WORLD_SIZE as `torch.distributed.run` would set them; the process group
+    rendezvous goes through a file in the job directory (no port to race for)."""
+    import shutil
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    import tempfile
+
+    def run_set(backend):
+        d = tempfile.mkdtemp(prefix="rk_bench_job_")
+        argv = [x for x in sys.argv[1:]]
+        for i, x in enumerate(argv):  # the set's backend replaces whatever the command line said
+            if x == "--dist-backend":
+                del argv[i:i + 2]
+                break
+            if x.startswith("--dist-backend="):
+                del argv[i]
+                break
+        argv += ["--dist-backend", backend]
+        procs = []
+        for r in range(a.gpus):
+            # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; without it RCCL's
+            # hipIpcGetMemHandle fails ("invalid argument").  The image exports it already; keep it if a caller dropped it.
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                       RK_BENCH_JOB_DIR=d, RK_BENCH_INIT_FILE=os.path.join(d, "pg_store"))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=open(os.path.join(d, f"rank{r}.out"), "wb"),
+                                          stderr=open(os.path.join(d, f"rank{r}.err"), "wb")))
+
+        def tail(r, n=4000):
+            try:
+                return open(os.path.join(d, f"rank{r}.err"), errors="replace").read()[-n:]
+            except OSError:
+                return ""
+
+        def stop_all():
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + 5.0
+            for p in procs:
+                try:
+                    p.wait(max(0.0, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+
+        pg_deadline = time.monotonic() + float(os.environ.get("RK_BENCH_PG_TIMEOUT", "180")) + 120.0
+        failed = None
+        try:
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                if bad:
+                    time.sleep(0.3)  # ranks that are failing for the same reason get to say so themselves
+                    failed = [(r, p.poll()) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                pg_up = all(os.path.exists(os.path.join(d, f"pg_done.{r}")) for r in range(a.gpus))
+                if not pg_up and backend != "none" and time.monotonic() > pg_deadline:
+                    failed = "pg-timeout"
+                    break
+                time.sleep(0.05)
+        finally:
+            stop_all()
+        # a failure of the process-group set-up itself (a rank said so with EX_PG_FAILED, or the group never came up)
+        in_pg = backend != "none" and (failed == "pg-timeout" or (failed is not None and any(c == EX_PG_FAILED for _, c in failed)))
+        if failed is None:
+            for r in range(a.gpus):  # the ranks' diagnostics, in rank order
+                sys.stderr.write(open(os.path.join(d, f"rank{r}.err"), errors="replace").read())
+            sys.stdout.write(open(os.path.join(d, "rank0.out"), errors="replace").read())
+            sys.stdout.flush()
+            shutil.rmtree(d, ignore_errors=True)
+            return 0, False
+        if failed == "pg-timeout":
+            sys.stderr.write(f"bench.py: the {backend} process group did not come up on every rank in time\n")
+        else:
+            for r, c in failed:
+                sys.stderr.write(f"bench.py: rank {r} exited with code {c}; its stderr ends:\n{tail(r)}\n")
+            sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {failed}; the other ranks were stopped\n")
+        sys.stderr.flush()
+        shutil.rmtree(d, ignore_errors=True)
+        return 1, in_pg
+
+    rc, in_pg = run_set(a.dist_backend)
+    if rc != 0 and in_pg and a.dist_backend in ("auto", "nccl"):
+        sys.stderr.write("bench.py: starting a fresh set of ranks with --dist-backend none (no process group; the data path has no collective)\n")
+        rc, _ = run_set("none")
+    return rc
+
+
+def per_rank_fields(sync, recs):
+    """what rank 0 adds to the JSON line about the individual ranks (their own reads/s: own reads / own time for its steps)"""
+    out = {"dist_backend": sync.backend if sync.note is None else f"{sync.backend} ({sync.note})"}
+    if recs and len(recs) > 1:
+        rates = [r["reads_per_s"] for r in recs]
+        out.update(per_rank=rates, per_rank_min=min(rates), per_rank_max=max(rates),
+                   per_rank_kernel_ms=[r["kernel_ms"] for r in recs], per_rank_device=[r.get("device_index") for r in recs])
+    return out
+
+
+def rehearse(a, rank, world):
+    """--rehearse-launch: everything bench.py does around the timed region (rank start, rendezvous, barriers, per-rank
+    results, the one JSON line) with a sleep in place of the placement step.  No GPU, no engine, no rate."""
+    die = os.environ.get("RK_BENCH_REHEARSE_DIE_RANK")  # tests: this rank dies before the rendezvous
+    if die is not None and int(die) == rank:
+        print(f"bench rank {rank}: dying before the rendezvous (RK_BENCH_REHEARSE_DIE_RANK)", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    sync = RankSync(rank, world, a.dist_backend, timeout_s=float(os.environ.get("RK_BENCH_SYNC_TIMEOUT", "600")))
+    sync.barrier()
+    t0 = time.monotonic()
+    for _ in range(a.steps):
+        time.sleep(0.005 * (1 + rank % 2))  # odd ranks are slower: the job's time must be theirs
+    t_own = time.monotonic()
+    sync.barrier()
+    t1 = time.monotonic()
+    n_reads = a.reads or 1000
+    elapsed, recs = sync.finish(t0, t1, dict(reads_per_s=n_reads * a.steps / (t_own - t0), kernel_ms=(t_own - t0) / a.steps * 1e3, device_index=None))
+    if rank == 0:
+        line = {"metric": "launcher rehearsal (no placement ran)", "value": None, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "data": "none: --rehearse-launch", "scaling": "weak"}
+        line.update(per_rank_fields(sync, recs))
+        print(json.dumps(line), flush=True)
+    sync.close()
     return 0
 
 
@@ -150,9 +431,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if os.environ.get("RK_BENCH_ECHO_RANK"):  # tests: proof that N separate rank processes were started
         print(f"bench rank {rank}/{world} pid {os.getpid()}", file=sys.stderr, flush=True)
+    if a.rehearse_launch:
+        return rehearse(a, rank, world)
     import torch
-    import torch.distributed as dist
-
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -161,13 +442,7 @@ def main():
         local_rank = a.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    sync = RankSync(rank, world, a.dist_backend, device=dev)
     n_gpus = world
 
     import rappas_amd as ra
@@ -264,26 +539,24 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sync.barrier()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    t0 = time.perf_counter()
+    t0 = time.monotonic()
     for s in range(a.steps):
         evs[s][0].record()
         step()
         evs[s][1].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    t_own = time.monotonic()
+    sync.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t1 = time.monotonic()
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    # t0 .. t1 is this rank's barrier-to-barrier time (MAX over ranks = the job's time); t_own is when its own steps were done
+    elapsed, per_rank = sync.finish(t0, t1, dict(reads_per_s=n_reads * a.steps / (t_own - t0), kernel_ms=kern_avg_s * 1e3,
+                                                  device=torch.cuda.get_device_name(local_rank), device_index=local_rank))
 
     if rank == 0:
         value = n_gpus * n_reads * a.steps / elapsed
@@ -317,6 +590,7 @@ def main():
                          "kernel_ms": kern_avg_s * 1e3, "kernel": db.kernel_name().split("<")[0]},
             "verified_vs_oracle": verified,
         }
+        line.update(per_rank_fields(sync, per_rank))
         if not a.no_pcie and n_gpus == 1:
             # ---- the boundary RAPPAS would call: host buffers in, host buffers out (never `value`) ----
             # pageable numpy arrays (what a JVM heap array looks like to the library), result arrays allocated once and reused
@@ -388,9 +662,7 @@ def main():
             line["cpu_baseline_all_cores"] = {"value": nall / cdt2, "unit": "reads/s", "cores": ncore, "kind": "port",
                                               "sample": f"first {nall} reads, {ncore} threads, {cdt2:.1f} s"}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    sync.close()
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 validation that needs no GPU.  No compute calls here."""
 import ctypes as C
 import os
+import time
 import re
 
 import numpy as np
@@ -155,14 +156,78 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
 
 
-def test_bench_gpus_n_launches_n_ranks_and_fails_if_a_rank_fails():
-    """without a GPU every rank exits with the 'needs an MI355X' error: the launcher must report that, not hide it"""
+def _bench(args, extra_env=None, timeout=300):
     import subprocess
     import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "RK_BENCH_JOB_DIR")}
     env["RK_BENCH_ECHO_RANK"] = "1"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "1000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--verify", "0"], env=env, capture_output=True, text=True, timeout=300)
+    env.update(extra_env or {})
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    return p, time.monotonic() - t0
+
+
+def test_bench_gpus_n_launches_n_ranks_and_fails_if_a_rank_fails():
+    """without a GPU every rank exits with the 'needs an MI355X' error: the launcher must report that, not hide it"""
+    p, _ = _bench(["--gpus", "2", "--reads", "1000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--verify", "0"])
     import torch
     if not torch.cuda.is_available():
-        assert p.returncode != 0 and "ranks failed" in p.stderr
-    assert p.stderr.count("bench rank") == 2 and "rank 0/2" in p.stderr and "rank 1/2" in p.stderr
+        assert p.returncode != 0 and "ranks failed" in p.stderr and "needs an MI355X" in p.stderr
+        assert p.stderr.count("bench rank") == 2 and "rank 0/2" in p.stderr and "rank 1/2" in p.stderr
+
+
+@pytest.mark.parametrize("backend,n", [("none", 4), ("none", 8), ("gloo", 4), ("gloo", 8), ("auto", 4)])
+def test_bench_rank_bookkeeping_with_4_and_8_ranks(backend, n):
+    """--rehearse-launch: N fresh rank processes, rendezvous, two barriers, MAX over ranks, per-rank results -- no GPU, no
+    placement.  Odd ranks take twice as long per step: the job's time must be the slow ranks' time.  `auto` has no RCCL
+    here, so every rank must take the same fall-back to `none`."""
+    import json
+    p, _ = _bench(["--gpus", str(n), "--rehearse-launch", "--dist-backend", backend, "--steps", "20"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["value"] is None and "rehearsal" in line["metric"]
+    assert line["dist_backend"].startswith("none" if backend == "auto" else backend)
+    assert len(line["per_rank"]) == n and line["per_rank_min"] == min(line["per_rank"])
+    assert line["per_rank"][0] > 1.5 * line["per_rank"][1]            # per-rank rates are the ranks' own
+    assert 10.0 <= line["ms_per_step"] < 14.0                         # the job runs at the slow ranks' 10 ms per step
+    assert sorted(int(x.split("/")[0]) for x in __import__("re").findall(r"bench rank (\d+/\d+)", p.stderr)) == list(range(n))
+
+
+@pytest.mark.parametrize("backend", ["gloo", "none"])
+def test_bench_a_rank_that_dies_before_the_rendezvous_ends_the_job_fast(backend):
+    """rank 2 of 4 dies before the rendezvous: the others would wait for it until the store / file time-out; the parent
+    must stop them and exit non-zero within seconds, naming the rank and showing its stderr"""
+    p, dt = _bench(["--gpus", "4", "--rehearse-launch", "--dist-backend", backend, "--steps", "5"], {"RK_BENCH_REHEARSE_DIE_RANK": "2"})
+    assert p.returncode != 0 and dt < 30.0, (p.returncode, dt)
+    assert "rank 2 exited with code 3" in p.stderr and "dying before the rendezvous" in p.stderr and "were stopped" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_a_process_group_that_cannot_be_set_up_is_retried_without_one():
+    """--dist-backend nccl without a GPU per rank: the set fails in the process-group set-up, the parent starts a fresh set
+    of ranks with --dist-backend none and the job completes"""
+    import json
+    p, _ = _bench(["--gpus", "2", "--rehearse-launch", "--dist-backend", "nccl", "--steps", "5"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "fresh set of ranks with --dist-backend none" in p.stderr
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["dist_backend"] == "none" and len(line["per_rank"]) == 2
+
+
+def test_bench_under_torch_distributed_run():
+    """the driver's launch line (torch.distributed.run, env:// rendezvous), rehearsed on CPU with gloo and with no process group"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    for backend in ("gloo", "none"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RK_BENCH_JOB_DIR")}
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--dist-backend", backend,
+                            "--steps", "5"], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["dist_backend"] == backend and len(line["per_rank"]) == 2

@@ -20,20 +20,32 @@ def run_bench(*args, timeout=900):
     return json.loads(lines[0])
 
 
-def test_gpus_2_starts_two_ranks_and_reports_the_whole_job():
-    """two ranks rehearsed on the one GPU of this box (gloo for the barrier / max-over-ranks; RCCL needs one GPU per rank)"""
-    common = ["--reads", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--verify", "300"]
+@pytest.mark.parametrize("backend", ["gloo", "none"])
+def test_gpus_2_starts_two_ranks_and_reports_the_whole_job(backend):
+    """two ranks rehearsed on the one GPU of this box: gloo for the barrier / max-over-ranks (RCCL needs one GPU per rank), and
+    with no process group at all (file rendezvous + monotonic stamps)"""
+    common = ["--reads", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pcie", "--verify", "300"]
     one = run_bench("--gpus", "1", *common)
-    two = run_bench("--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", *common)
+    two = run_bench("--gpus", "2", "--force-device", "0", "--dist-backend", backend, *common)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
-    assert two["config"]["sharding"].startswith("reads x2")
+    assert two["config"]["sharding"].startswith("reads x2") and two["dist_backend"] == backend
     # value = reads of ALL ranks / max-over-ranks time
     assert abs(two["value"] - 2 * 200000 * 3 / (two["ms_per_step"] * 3 / 1e3)) / two["value"] < 1e-6
     # both ranks share one GPU here, so the whole-job rate stays near the one-rank rate (it would double on two GPUs)
     assert 0.4 * one["value"] < two["value"] < 1.6 * one["value"], (one["value"], two["value"])
+    # every rank reports its own rate; no rank can be slower than the whole job's per-rank share
+    assert len(two["per_rank"]) == 2 and two["per_rank_min"] * 2 >= two["value"] * 0.999
     for line in (one, two):
         assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
         assert line["verified_vs_oracle"]["reads"] == 300
+
+
+def test_auto_backend_with_two_ranks_on_one_gpu_ends_with_a_result():
+    """`auto` tries RCCL first; two ranks on ONE GPU cannot form an RCCL communicator, so this is the fall-back the first
+    real multi-GPU run would take if RCCL could not be set up: either in-process (vote) or by a fresh set of ranks"""
+    line = run_bench("--gpus", "2", "--force-device", "0", "--reads", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                     "--no-pcie", "--verify", "0", timeout=900)
+    assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2 and line["dist_backend"].split()[0] in ("none", "nccl")
 
 
 def test_world_size_mismatch_is_an_error():
