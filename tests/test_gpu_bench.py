@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args, timeout=900):
+def run_bench(*args, timeout=900, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -44,7 +45,7 @@ def test_auto_backend_with_two_ranks_on_one_gpu_ends_with_a_result():
     """`auto` tries RCCL first; two ranks on ONE GPU cannot form an RCCL communicator, so this is the fall-back the first
     real multi-GPU run would take if RCCL could not be set up: either in-process (vote) or by a fresh set of ranks"""
     line = run_bench("--gpus", "2", "--force-device", "0", "--reads", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                     "--no-pcie", "--verify", "0", timeout=900)
+                     "--no-pcie", "--verify", "0", timeout=900, RK_BENCH_PG_TIMEOUT="45")
     assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2 and line["dist_backend"].split()[0] in ("none", "nccl")
 
 
