@@ -108,12 +108,28 @@ def lib_path():
     return os.environ.get("RK_LIB") or _build.ENGINE_SO
 
 
+_DEV = None
+
+
+def load_dev():
+    """The -DRK_DEV_KNOBS build (librappas_place_dev.so): the only build that reads the developer / test environment knobs.
+    Tests that need a knob switch to it with the `dev_lib` fixture (tests/conftest.py); nothing in the package does."""
+    global _DEV
+    if _DEV is None:
+        _DEV = _open(os.environ.get("RK_LIB") or _build.DEV_SO, C.RTLD_LOCAL)
+    return _DEV
+
+
 def load():
     """Load librappas_place.so.  Fails loudly if the HIP extension has not been built: no fallback."""
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = lib_path()
+    _LIB = _open(lib_path(), C.RTLD_GLOBAL)
+    return _LIB
+
+
+def _open(path, mode):
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build the gfx950 engine first (python -m rappas_amd.build); "
                            "there is no CPU fallback for the placement path")
@@ -123,14 +139,13 @@ def load():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is plumbing, the engine itself does not need it
         pass
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=mode)
     for name, (res, args) in EXPORTS.items():
         if name.startswith("rk_buil") and os.environ.get("RK_LIB") and not hasattr(lib, name):
             continue  # developer timing builds (scripts/) compile the placement unit only
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _LIB = lib
     return lib
 
 

@@ -619,7 +619,7 @@ static int build_db_impl(const rk_build_desc *d, rk_built_db *out) {
     u64 total_tuples = 0, total_visits = 0;
     double explore_total = 0.0, reduce_total = 0.0;
     u32 batch = d->n_nodes;
-    if (const char *e = getenv("RK_BUILD_BATCH_NODES")) batch = (u32)atoi(e);  // developer / test knob
+    if (const char *e = rk_knob("RK_BUILD_BATCH_NODES")) batch = (u32)atoi(e);  // developer / test knob
     if (batch < 1) batch = 1;
     u32 node0 = 0;
     double slots_per_task = -1.0;  // measured on the batches done so far (explorers register 0 .. thousands of words each)
@@ -627,7 +627,7 @@ static int build_db_impl(const rk_build_desc *d, rk_built_db *out) {
     while (node0 < d->n_nodes && n_pos) {
         u32 nb = std::min(batch, d->n_nodes - node0);
         // nothing measured yet and too many explorers to size the buffer generously: measure on a small first batch
-        if (slots_per_task < 0 && (u64)nb * n_pos * generous > target_slots && !getenv("RK_BUILD_BATCH_NODES"))
+        if (slots_per_task < 0 && (u64)nb * n_pos * generous > target_slots && !rk_knob("RK_BUILD_BATCH_NODES"))
             nb = std::max<u32>(1, (u32)std::min<u64>(nb, target_slots / ((u64)n_pos * generous)));
         a.task_base = (u64)node0 * n_pos;
         a.n_tasks = (u64)nb * n_pos;
@@ -646,10 +646,10 @@ static int build_db_impl(const rk_build_desc *d, rk_built_db *out) {
             // (a shorter in-register tail does not help wide alphabets: measured 32-34 Gvisits/s for INL = 1, 2, 3 on AA k=5
             //  before the chunked append, which is what that case was waiting for)
             int inl = 3;
-            if (const char *e = getenv("RK_BUILD_INLINE_LEVELS")) inl = atoi(e);  // developer knob
+            if (const char *e = rk_knob("RK_BUILD_INLINE_LEVELS")) inl = atoi(e);  // developer knob
             const dim3 grid(blocks), block(64 * BUILD_WAVES_PER_BLOCK);
             // whole site rows in registers for the two alphabets RAPPAS has (4 / 20 states); anything else: per-visit loads
-            const int vec = getenv("RK_BUILD_NO_VEC") ? 0 : (d->n_states == 4 ? 4 : (d->n_states == 20 ? 20 : 0));
+            const int vec = rk_knob("RK_BUILD_NO_VEC") ? 0 : (d->n_states == 4 ? 4 : (d->n_states == 20 ? 20 : 0));
 #define RK_LAUNCH_EXPLORE(I)                                                                                \
     do {                                                                                                    \
         if (a.do_gap) {                                                                                     \
@@ -727,7 +727,7 @@ static int build_db_impl(const rk_build_desc *d, rk_built_db *out) {
         reduce_total += ms;
         // next batch: aim at target_slots from what this one produced per node
         slots_per_task = std::max(1.0, (double)n_slots / (double)a.n_tasks);
-        if (!getenv("RK_BUILD_BATCH_NODES")) {
+        if (!rk_knob("RK_BUILD_BATCH_NODES")) {
             const u64 per_node = std::max<u64>(1, n_slots / nb);
             const u64 want = std::max<u64>(1, target_slots / per_node);
             batch = (u32)std::min<u64>(want, d->n_nodes);

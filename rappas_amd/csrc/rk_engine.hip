@@ -105,7 +105,7 @@ static int resident_blocks(K kern, int block_threads, size_t lds, uint64_t by_ld
     }
     if (n < 1) return fail(RK_ERR_UNSUPPORTED, "internal: kernel does not fit a CU (%d threads, %zu B of LDS per block)", block_threads, lds);
     out = by_lds < (uint64_t)n ? by_lds : (uint64_t)n;
-    static const bool trace = getenv("RK_TRACE_GRID") != nullptr;  // developer knob
+    static const bool trace = rk_knob("RK_TRACE_GRID") != nullptr;  // developer knob
     if (trace) fprintf(stderr, "[rk] grid: %d threads, %zu B LDS per block -> %d resident per CU (by LDS size %llu)\n", block_threads, lds, n, (unsigned long long)by_lds);
     return RK_OK;
 }
@@ -256,7 +256,7 @@ constexpr uint64_t RK_WINDOW_MAX_BLOB = 1ull << 31;  // list items carry a 24-bi
 // in two or three waves per CU (beyond 8 192 branches; scripts/dense_rows_mid_tree.py, every k-mer present with rows of 30 / 60
 // entries: 9 001 branches 66 / 45 against 41 / 36, 15 999: 49 / 36 against 17 / 15; longer rows there take the large-tree image)
 static inline bool windows_pay(uint32_t nb, uint64_t blob_units, uint64_t space) {
-    if (getenv("RK_WINDOW_ALWAYS")) return true;  // developer / test knob: the windowed kernel whatever the row density
+    if (rk_knob("RK_WINDOW_ALWAYS")) return true;  // developer / test knob: the windowed kernel whatever the row density
     return 5 * blob_units <= 11 * space || nb > RK_WG_MIN_BRANCHES;
 }
 struct WindowPlan {
@@ -444,10 +444,10 @@ static int build_table(uint32_t &mode, uint64_t space, uint64_t n_keys, bool ind
     // 4-bit unit counts (24 k-mers per block, 0.67 bytes per k-mer) whenever no row exceeds 15 units = 240 entries: half the table
     // means its lines are re-touched twice as often and survive the rows streaming through the same L2 sets (C2: 15 of a read's 141
     // probes missed the L2 with the byte form)
-    static const bool bytes_only = getenv("RK_COMPACT_BYTES") != nullptr;  // developer knob: A/B against the byte form
+    static const bool bytes_only = rk_knob("RK_COMPACT_BYTES") != nullptr;  // developer knob: A/B against the byte form
     // ... where rows stream at all: with fewer than one row unit per two k-mer codes (C4: 0.13) the probes outnumber the row lines,
     // nothing evicts the table and the longer decode is all that is left (C4: 5.37e8 against 5.52e8 reads/s)
-    static const bool nibbles_always = getenv("RK_COMPACT_NIBBLES") != nullptr;  // developer knob: the half-size form whatever the density
+    static const bool nibbles_always = rk_knob("RK_COMPACT_NIBBLES") != nullptr;  // developer knob: the half-size form whatever the density
     nib = mode == RK_TABLE_DIRECT && max_units <= 15 && (2 * blob_units >= space || nibbles_always) && !bytes_only;
     try {
         if (mode == RK_TABLE_DIRECT) {
@@ -864,7 +864,7 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
     std::vector<std::string> msgs(n_dbs);
     std::vector<rk_counters> cts(n_dbs);
     // developer / test knob: the first attempt of this shard reports a device failure (exercises the re-queue below)
-    const int inject = getenv("RK_TEST_FAIL_SHARD") ? atoi(getenv("RK_TEST_FAIL_SHARD")) : -1;
+    const int inject = rk_knob("RK_TEST_FAIL_SHARD") ? atoi(rk_knob("RK_TEST_FAIL_SHARD")) : -1;
     auto run_shard = [&](uint32_t g, uint32_t on, bool first_attempt) {  // shard g of the batch on handle `on`, in the calling thread
         const uint64_t lo = n_reads * g / n_dbs, hi = n_reads * (g + 1) / n_dbs;
         cts[g] = rk_counters{};
@@ -990,7 +990,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         cap = (uint32_t)(c > 256 ? 256 : c);
         if (cap < min_cap) cap = min_cap;
     }
-    if (const char *e = getenv("RK_LIST_CAP")) {  // developer knob: trade hit-list room for occupancy
+    if (const char *e = rk_knob("RK_LIST_CAP")) {  // developer knob: trade hit-list room for occupancy
         uint32_t v = (uint32_t)atoi(e);
         if (v >= min_cap && v <= 4096) cap = v;
     }
@@ -1001,7 +1001,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         return fail(RK_ERR_UNSUPPORTED, "n_branches=%u needs %zu B of LDS per read, more than one CU has (%zu B)", nb, g.lds_per_wave, db->lds_per_cu);
     uint32_t w = (uint32_t)(db->lds_per_cu / g.lds_per_wave);
     g.waves_per_cu = w > 32 ? 32 : w;
-    if (const char *e = getenv("RK_WAVES_PER_CU")) {  // developer knob for occupancy experiments
+    if (const char *e = rk_knob("RK_WAVES_PER_CU")) {  // developer knob for occupancy experiments
         uint32_t v = (uint32_t)atoi(e);
         if (v >= 1 && v < g.waves_per_cu) g.waves_per_cu = v;
     }
@@ -1010,7 +1010,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
 
 // 16 lanes per read, direct table, 32-bit row offsets, packed record of <= 16 words: the tile-pipelined kernel
 static bool use_pipelined16(const rk_db *db, const Geometry &g, const PlaceArgs &args) {
-    static const bool off = getenv("RK_NO_PIPE") != nullptr;  // developer knob: A/B against place_packed_kernel
+    static const bool off = rk_knob("RK_NO_PIPE") != nullptr;  // developer knob: A/B against place_packed_kernel
     return !off && g.G == 16 && db->info.table_mode != RK_TABLE_HASH && db->info.rows_bytes < ROWS_FIT32_LIMIT && args.words_per_read <= 16;
 }
 
@@ -1058,7 +1058,7 @@ static int launch_b(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipS
 // mid-size trees: the windowed kernel whenever the image carries window spans, nobody forced a lane-group width, the K best
 // of the tree fit one 16-lane row (keep_at_most <= 16) and the packed record fits one word per lane
 static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_per_read) {
-    static const bool off = getenv("RK_NO_WINDOW") != nullptr;  // developer knob: A/B against the dense kernels
+    static const bool off = rk_knob("RK_NO_WINDOW") != nullptr;  // developer knob: A/B against the dense kernels
     // (scripts/keep_at_most_sweep.py, windowed against dense, Mreads/s: 3 999 branches K = 9 / 12 / 16: 156 / 141 / 105 against 91 / 84 / 76)
     // Records of more than 16 words (the kernel then reads its k-mers from memory, and a long read is emitted in several window
     // ranges): ahead of the dense kernels while a read has fewer symbols than about a ninth of the tree's branches
@@ -1123,7 +1123,7 @@ struct WgGeometry {
 static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
     const uint32_t nb = db->info.n_branches;
     uint32_t min_pass = 1;
-    if (const char *e = getenv("RK_WG_PASSES")) min_pass = (uint32_t)atoi(e);  // developer / test knob: force 2 or 4 passes on a tree that fits in one
+    if (const char *e = rk_knob("RK_WG_PASSES")) min_pass = (uint32_t)atoi(e);  // developer / test knob: force 2 or 4 passes on a tree that fits in one
     for (uint32_t P : {1u, 2u, 4u}) {
         if (P < min_pass) continue;
         const uint32_t span = 32 / P;
@@ -1202,7 +1202,7 @@ static int launch_ascii_v(const rk_db *db, PlaceArgs args, AmbArgs m, hipStream_
     const size_t list_bytes = (size_t)ASCII_LIST_CAP * 8;
     uint32_t s_win = nb;
     size_t chunk;
-    const bool force_windows = db->indexed && getenv("RK_WG_PASSES") && atoi(getenv("RK_WG_PASSES")) > 1;  // same test knob
+    const bool force_windows = db->indexed && rk_knob("RK_WG_PASSES") && atoi(rk_knob("RK_WG_PASSES")) > 1;  // same test knob
     if (!force_windows && (size_t)((nb + 4) & ~3u) * 4 + list_bytes + 8 * 64 <= db->lds_per_cu) {
         args.s_stride = (nb + 4) & ~3u;
         const size_t fixed = (size_t)args.s_stride * 4 + list_bytes;
@@ -1400,7 +1400,7 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     // chunks of 2^18 reads: the kernel still fills the chip (2^16 tiles for 2 048 waves) and the part of a call that nothing
     // overlaps -- the first chunk's upload, the last chunk's download and drain -- stays short
     uint64_t max_chunk_reads = 1ull << 18;
-    if (const char *e = getenv("RK_CHUNK_READS")) {  // developer knob
+    if (const char *e = rk_knob("RK_CHUNK_READS")) {  // developer knob
         const long v = atol(e);
         if (v >= 1024) max_chunk_reads = (uint64_t)v;
     }
@@ -1453,7 +1453,7 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     unsigned chunk_no = 0;
     int status = RK_OK;
     // developer knob: RK_HOST_TIMING=1 prints where the host thread of this call spent its time (stderr)
-    const bool timing = getenv("RK_HOST_TIMING") != nullptr;
+    const bool timing = rk_knob("RK_HOST_TIMING") != nullptr;
     double t_wait = 0, t_drain = 0, t_stage = 0, t_enq = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // Three workspaces in flight.  This thread stages and enqueues chunk c while a second host thread waits for the stream

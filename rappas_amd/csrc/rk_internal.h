@@ -1,6 +1,16 @@
 // rk_internal.h -- shared between the translation units of librappas_place.so (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+// Developer / test knobs exist only in builds with -DRK_DEV_KNOBS (rappas_amd/librappas_place_dev.so, the
+// variant builds of scripts/).  The product library reads NO environment variable: a JVM hands its whole environment down.
+#ifdef RK_DEV_KNOBS
+static inline const char *rk_knob(const char *name) { return getenv(name); }
+#else
+static inline const char *rk_knob(const char *) { return nullptr; }
+#endif
+
 
 namespace rk {
 // sets the thread-local message rk_last_error() returns and hands back `code`

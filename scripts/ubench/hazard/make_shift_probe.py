@@ -30,6 +30,20 @@ def tests():
       "v_add_f64 v[6:7], v[20:21], v[20:21]", "v_add_f64 v[8:9], v[22:23], v[22:23]")
     S("mul_lo_u32_src_top", ["v_mov_b32_e32 v23, 3"], "v_mul_lo_u32 v6, v4, v10\n\tv_mov_b32_e32 v7, 0", "v_mul_lo_u32 v8, v4, v23\n\tv_mov_b32_e32 v9, 0")
     S("alignbit_count_top", ["v_mov_b32_e32 v23, 3"], "v_alignbit_b32 v6, v5, v4, v10\n\tv_mov_b32_e32 v7, 0", "v_alignbit_b32 v8, v5, v4, v23\n\tv_mov_b32_e32 v9, 0")
+    # the last USED register below an allocation boundary (22 or 23 registers used, 24 allocated): is the limit the allocation's?
+    for nn in (22, 23):
+        t["lshr_count_lastused_%d" % nn] = (nn, ["v_mov_b32_e32 v%d, 3" % (nn - 1)], "v_lshrrev_b64 v[6:7], v10, v[4:5]", "v_lshrrev_b64 v[8:9], v%d, v[4:5]" % (nn - 1), [])
+    S("lshl_count_top", ["v_mov_b32_e32 v23, 3"], "v_lshlrev_b64 v[6:7], v10, v[4:5]", "v_lshlrev_b64 v[8:9], v23, v[4:5]")
+    S("ashr_count_top", ["v_mov_b32_e32 v23, 3"], "v_ashrrev_i64 v[6:7], v10, v[4:5]", "v_ashrrev_i64 v[8:9], v23, v[4:5]")
+    S("cvt_f64_u32_src_top", ["v_mov_b32_e32 v23, v4", "v_mov_b32_e32 v20, v4"], "v_cvt_f64_u32_e32 v[6:7], v20", "v_cvt_f64_u32_e32 v[8:9], v23")
+    S("cvt_f64_i32_src_top", ["v_mov_b32_e32 v23, v4", "v_mov_b32_e32 v20, v4"], "v_cvt_f64_i32_e32 v[6:7], v20", "v_cvt_f64_i32_e32 v[8:9], v23")
+    S("cvt_f64_f32_src_top", ["v_cvt_f32_u32_e32 v23, v1", "v_cvt_f32_u32_e32 v20, v1"], "v_cvt_f64_f32_e32 v[6:7], v20", "v_cvt_f64_f32_e32 v[8:9], v23")
+    S("ldexp_f64_exp_top", ["v_mov_b32_e32 v23, 3", "v_mov_b32_e32 v20, v4", "v_mov_b32_e32 v21, 0x3ff00000"], "v_ldexp_f64 v[6:7], v[20:21], v10", "v_ldexp_f64 v[8:9], v[20:21], v23")
+    S("mad_u64_u32_src0_top", ["v_mov_b32_e32 v23, 3"], "v_mad_u64_u32 v[6:7], s[8:9], v10, v4, v[4:5]", "v_mad_u64_u32 v[8:9], s[8:9], v23, v4, v[4:5]")
+    S("mad_i64_i32_src0_top", ["v_mov_b32_e32 v23, 3"], "v_mad_i64_i32 v[6:7], s[8:9], v10, v4, v[4:5]", "v_mad_i64_i32 v[8:9], s[8:9], v23, v4, v[4:5]")
+    S("cvt_f32_f64_dst_top", ["v_mov_b32_e32 v20, v4", "v_mov_b32_e32 v21, 0x3ff00000"], "v_cvt_f32_f64_e32 v6, v[20:21]\n\tv_mov_b32_e32 v7, 0", "v_cvt_f32_f64_e32 v23, v[20:21]\n\tv_mov_b32_e32 v8, v23\n\tv_mov_b32_e32 v9, 0")
+    S("cvt_u32_f64_dst_top", ["v_mov_b32_e32 v20, v4", "v_mov_b32_e32 v21, 0x40f00000"], "v_cvt_u32_f64_e32 v6, v[20:21]\n\tv_mov_b32_e32 v7, 0", "v_cvt_u32_f64_e32 v23, v[20:21]\n\tv_mov_b32_e32 v8, v23\n\tv_mov_b32_e32 v9, 0")
+    S("frexp_exp_i32_f64_dst_top", ["v_mov_b32_e32 v20, v4", "v_mov_b32_e32 v21, 0x40f00000"], "v_frexp_exp_i32_f64_e32 v6, v[20:21]\n\tv_mov_b32_e32 v7, 0", "v_frexp_exp_i32_f64_e32 v23, v[20:21]\n\tv_mov_b32_e32 v8, v23\n\tv_mov_b32_e32 v9, 0")
     return t
 
 
@@ -62,7 +76,7 @@ def gen(n, setup, ref, test, between):
                         "\tglobal_store_dwordx4 v[12:13], v[6:9], off offset:16", ""])
     body = body[:a] + code + body[b:]
     body = body.replace("alias_probe", "shift_probe").replace("VGPR aliasing probe", "operand-in-the-last-VGPR probe")
-    return body.format(n=n, acc=n, init="", check="", top=n - 1, top1=n - 2, topx="0")
+    return body.format(n=n, acc=(n + 3) // 4 * 4, init="", check="", top=n - 1, top1=n - 2, topx="0")
 
 
 if __name__ == "__main__":

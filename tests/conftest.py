@@ -33,3 +33,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def dev_lib(monkeypatch):
+    """Route this test's engine calls to librappas_place_dev.so (built with -DRK_DEV_KNOBS): the product library reads no
+    environment variable, so tests that steer the engine with a developer knob (RK_WG_PASSES, RK_WINDOW_ALWAYS, the shard-failure
+    injector ...) must say so by asking for this fixture.  Handles created before the test keep the library they were made with."""
+    from rappas_amd import _lib
+    _lib.load()
+    monkeypatch.setattr(_lib, "_LIB", _lib.load_dev())
+    yield

@@ -102,7 +102,7 @@ def test_built_db_places_reads_drawn_from_its_own_posteriors():
     db.close()
 
 
-def test_node_batches_fold_into_the_same_database(monkeypatch):
+def test_node_batches_fold_into_the_same_database(monkeypatch, dev_lib):
     """Large inputs are explored in node batches whose reduced (k-mer, branch) -> best score sets are merged; forcing tiny
     batches must give the identical database."""
     states, pp, nb = synth.make_pp_tables(4, 14, 90, seed=9, n_branches=5)  # several nodes per branch: maxima across batches

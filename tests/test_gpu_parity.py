@@ -505,7 +505,7 @@ def test_trees_between_one_and_two_lds(n_branches):
 
 
 @pytest.mark.parametrize("passes", ["2", "4"])
-def test_forced_passes_equal_the_single_pass_result(passes, monkeypatch):
+def test_forced_passes_equal_the_single_pass_result(passes, monkeypatch, dev_lib):
     """a C5-sized tree (19 999 branches fits one pass) run with 2 and 4 forced passes: identical placements"""
     sdb = _big_tree_db(19999, 300, seed=5)
     odb = O.OracleDB.from_synth(sdb)
@@ -517,7 +517,7 @@ def test_forced_passes_equal_the_single_pass_result(passes, monkeypatch):
     assert np.array_equal(one.n_rows, many.n_rows) and np.array_equal(one.lwr, many.lwr)
 
 
-def test_failed_shard_is_requeued_on_a_healthy_device(c2_small, monkeypatch):
+def test_failed_shard_is_requeued_on_a_healthy_device(c2_small, monkeypatch, dev_lib):
     """a per-GPU failure re-queues the shard on another GPU.  Shard 1 of 3 reports a device failure on its
     first attempt (test knob); the call must still succeed, give the single-call results and name the device in rk_last_error."""
     sdb, odb = c2_small
@@ -709,7 +709,7 @@ def test_windowed_kernel_rows_scattered_over_all_windows():
     assert st["placed"] == 1500
 
 
-def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window(monkeypatch):
+def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window(monkeypatch, dev_lib):
     """250-bp reads against a database where every k-mer has a row of ~40 entries: ~700 row units per read, more than the main
     list holds -> window ranges and the per-window probe with the row cursor (rows this dense normally take the dense kernels:
     RK_WINDOW_ALWAYS keeps the windowed image)"""
@@ -721,7 +721,7 @@ def test_windowed_kernel_reads_too_big_for_the_item_list_probe_once_per_window(m
 
 
 @pytest.mark.parametrize("n_branches,mean_row", [(7999, 26), (3999, 30), (15999, 18)])
-def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, mean_row, monkeypatch):
+def test_windowed_kernel_reads_that_fit_the_item_list_in_two_halves(n_branches, mean_row, monkeypatch, dev_lib):
     """every k-mer hits a row of two units on average: ~300 row units per 150-bp read, more than the main list holds for the whole
     tree but not for half of its windows -> the tile is emitted once per half; mixed with short reads (fit whole) and 250-bp reads
     (do not fit a half either: the per-window probe)"""
@@ -805,7 +805,7 @@ def test_windowed_kernel_keep_at_most_beyond_eight(n_branches, K):
     run_case(cdb, O.OracleDB.from_synth(cdb), seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0)
 
 
-def test_windowed_and_dense_kernels_agree(monkeypatch):
+def test_windowed_and_dense_kernels_agree():
     sdb = synth.make_db(4, 8, 4500, 40000, 520000, seed=77)
     seq, off = synth.make_reads(4, 20000, 150, seed=5)
     db = ra.PhyloKmerDB.from_synth(sdb)
