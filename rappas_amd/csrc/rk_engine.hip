@@ -3,6 +3,7 @@
 // Product path: there is NO CPU fallback in this file; every compute entry point needs a HIP device.
 #include "rk_kernels.hip"
 #include "rk_internal.h"
+#include "rk_pack_host.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -13,6 +14,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -223,6 +225,64 @@ void parallel_copy(void *dst, const void *src, size_t bytes) {
     }
     memcpy(dst, src, bytes / parts);
     for (std::thread &t : th) t.join();
+}
+
+// A few worker threads that live for the duration of ONE host call: run(fn) executes fn(part, parts) on every worker and on the
+// caller and returns when all are done (a chunk of 2^18 reads is packed in under a millisecond -- starting threads per chunk would
+// cost as much as the work).  Joined in the destructor, so no path out of the call leaves a thread behind.
+class ForkJoin {
+  public:
+    explicit ForkJoin(unsigned workers) {
+        for (unsigned i = 0; i < workers; i++) th_.emplace_back([this, i]() { loop(i + 1); });
+    }
+    ~ForkJoin() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    unsigned parts() const { return (unsigned)th_.size() + 1; }
+    void run(const std::function<void(unsigned, unsigned)> &fn) {
+        if (th_.empty()) { fn(0, 1); return; }
+        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; left_ = (unsigned)th_.size(); gen_++; }
+        cv_.notify_all();
+        fn(0, parts());
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&]() { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void loop(unsigned me) {
+        uint64_t seen = 0;
+        while (true) {
+            const std::function<void(unsigned, unsigned)> *fn;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)(me, parts());
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--left_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned, unsigned)> *fn_ = nullptr;
+    uint64_t gen_ = 0;
+    unsigned left_ = 0;
+    bool stop_ = false;
+};
+
+unsigned host_threads(uint64_t n_reads, unsigned asked) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned T = asked ? asked : std::max(1u, std::min(hw ? hw : 1u, 16u));
+    return n_reads < 4096 ? 1u : T;
 }
 }  // namespace
 
@@ -864,17 +924,23 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
     std::vector<std::string> msgs(n_dbs);
     std::vector<rk_counters> cts(n_dbs);
     // developer / test knob: the first attempt of this shard reports a device failure (exercises the re-queue below)
+#ifdef RK_DEV_KNOBS
     const int inject = rk_knob("RK_TEST_FAIL_SHARD") ? atoi(rk_knob("RK_TEST_FAIL_SHARD")) : -1;
+#endif
     auto run_shard = [&](uint32_t g, uint32_t on, bool first_attempt) {  // shard g of the batch on handle `on`, in the calling thread
         const uint64_t lo = n_reads * g / n_dbs, hi = n_reads * (g + 1) / n_dbs;
         cts[g] = rk_counters{};
         codes[g] = RK_OK;
         if (hi == lo) return;
+#ifdef RK_DEV_KNOBS
         if (first_attempt && inject == (int)g) {
             codes[g] = RK_ERR_HIP;
             msgs[g] = "injected failure (RK_TEST_FAIL_SHARD)";
             return;
         }
+#else
+        (void)first_attempt;
+#endif
         rk_result r{out->n_rows + lo, out->branch + lo * K, out->score + lo * K, out->lwr + lo * K, out->flags + lo};
         codes[g] = rk_place_batch(dbs[on], p, hi - lo, seq_ascii, seq_off + lo, &r, &cts[g]);
         if (codes[g] != RK_OK) msgs[g] = rk_last_error();  // the message lives in this thread: hand it over
