@@ -618,16 +618,20 @@ def main():
                                   ra.host_alloc((npc, K), np.float64), ra.host_alloc(npc, np.uint32), {})
             r_pinned = timed(lambda: pp.processQueriesPacked(p_packed, fixed_len=rlen, keepAtMost=K, out=p_out))
             same = same and bool(np.array_equal(p_out.n_rows, dev_n))
+            pk_out = pp.pack_reads_host(h_seq, h_off, max_len=rlen)           # (first call: the output pages are touched here)
+            same = same and bool(np.array_equal(pk_out[0], h_packed))
             t0 = time.perf_counter()
-            pp.pack_reads_host(h_seq, h_off, max_len=rlen)
-            r_pack = npc / (time.perf_counter() - t0)
+            for _ in range(5):
+                pp.pack_reads_host(h_seq, h_off, max_len=rlen, out=pk_out)
+            r_pack = 5 * npc / (time.perf_counter() - t0)
             out_b = 1 + K * 14 + 4
             line["pcie_inclusive"] = {
                 "packed_host": {"value": r_packed, "unit": "reads/s", "entry": "rk_place_batch_packed", "bytes_in_per_read": wpr * 4, "bytes_out_per_read": out_b},
                 "packed_host_page_locked": {"value": r_pinned, "unit": "reads/s", "entry": "rk_place_batch_packed over rk_host_alloc buffers",
                                             "bytes_in_per_read": wpr * 4, "bytes_out_per_read": out_b},
                 "ascii_host": {"value": r_ascii, "unit": "reads/s", "entry": "rk_place_batch", "bytes_in_per_read": rlen + 8, "bytes_out_per_read": out_b},
-                "host_packer": {"value": r_pack, "unit": "reads/s", "entry": "rk_pack_reads_host", "threads": min(os.cpu_count() or 1, 16)},
+                "host_packer": {"value": r_pack, "unit": "reads/s", "entry": "rk_pack_reads_host (AVX2 + BMI2 blocks of 32 symbols), output arrays reused, 5 calls",
+                                "threads": min(os.cpu_count() or 1, 16)},
                 "sample": f"first {npc} reads of the batch, pageable host arrays unless named page-locked, result arrays reused, 5 calls after two warm-ups",
                 "equals_device_path": same}
         if not a.no_cpu_baseline and n_gpus == 1:

@@ -174,6 +174,11 @@ int rk_place_batch_packed(rk_db *db, const rk_params *p, uint64_t n_reads, const
                           const uint64_t *seq_off, rk_result *out, rk_counters *counters);
 int rk_pack_reads_host(const rk_db *db, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off, uint32_t words_per_read,
                        uint32_t *packed, uint32_t *lens, uint32_t *flags, uint32_t n_threads);
+/* The same packer without a database handle (no GPU involved): `alphabet` RK_ALPHABET_DNA / RK_ALPHABET_AA, `convert_uo` the
+ * database's --convertUO switch (AAStates.java:118-123), `k` for RK_FLAG_TOO_SHORT.  words_per_read >= ceil(longest read * b / 32),
+ * b = 2 (DNA) / 5 (amino acids); longer reads are cut and flagged RK_FLAG_TOO_LONG. */
+int rk_pack_reads(uint32_t alphabet, int convert_uo, uint32_t k, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off,
+                  uint32_t words_per_read, uint32_t *packed, uint32_t *lens, uint32_t *flags, uint32_t n_threads);
 
 /* The same over several GPUs from ONE host process (RAPPAS is a single JVM): dbs[g] are handles of the same database created
  * on different devices (rk_db_create with desc.device = g); the batch is cut into n_dbs contiguous shards, shard g goes to

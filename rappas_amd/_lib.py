@@ -86,6 +86,8 @@ EXPORTS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rk_result), C.POINTER(rk_counters)]),
     "rk_pack_reads_host": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_uint32]),
+    "rk_pack_reads": (C.c_int, [C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_uint32]),
     "rk_place_batch_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rk_params), C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.POINTER(rk_result), C.POINTER(rk_counters)]),
     "rk_host_alloc": (C.c_void_p, [C.c_uint64]),

@@ -36,7 +36,7 @@ def _stale(target, sources):
 
 
 def engine_sources():
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp"))]
     srcs.append(os.path.join(ROOT, "include", "rappas_place.h"))
     return srcs
 
@@ -47,6 +47,7 @@ def build_engine(force=False, verbose=False):
     if not force and not _stale(ENGINE_SO, srcs) and not _stale(DEV_SO, srcs):
         return ENGINE_SO
     units = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and f != "rk_kernels.hip"]  # rk_kernels.hip is #included by rk_engine.hip
+    host_units = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".cpp")]  # host-only code (the SIMD read packer): plain C++
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
     flags = [f for f in HIPCC_FLAGS if f != "-shared"]
@@ -58,14 +59,21 @@ def build_engine(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((tag, cmd, obj, subprocess.Popen(cmd, cwd=ROOT)))
-    objs = {"": [], "_dev": []}
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    for u in host_units:  # no knobs in there: one object serves both libraries
+        obj = os.path.join(objdir, u.replace(".cpp", ".o"))
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", "-o", obj, os.path.join(CSRC, u)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(("both", cmd, obj, subprocess.Popen(cmd, cwd=ROOT)))
+    objs = {"": [], "_dev": [], "both": []}
     for tag, cmd, obj, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
         objs[tag].append(obj)
     for tag, so in (("", ENGINE_SO), ("_dev", DEV_SO)):
         # -Bsymbolic: calls between the library's own entry points stay inside it when both builds are loaded into one process
-        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so] + objs[tag]
+        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so] + objs[tag] + objs["both"]
         if verbose:
             print(" ".join(link), flush=True)
         subprocess.run(link, check=True, cwd=ROOT)

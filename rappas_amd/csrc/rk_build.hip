@@ -524,6 +524,7 @@ extern "C" void rk_built_free(rk_built_db *b) {
 static int build_db_impl(const rk_build_desc *d, rk_built_db *out);
 
 extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
+    RK_GUARD_BEGIN
     if (!d || !out) return fail_msg(RK_ERR_INVALID, "rk_build_db: null argument");
     memset(out, 0, sizeof(*out));
     int prev = -1;
@@ -532,6 +533,7 @@ extern "C" int rk_build_db(const rk_build_desc *d, rk_built_db *out) {
     if (rc != RK_OK) rk_built_free(out);  // nothing half-built is handed back
     if (prev >= 0) (void)hipSetDevice(prev);
     return rc;
+    RK_GUARD_END("rk_build_db")
 }
 
 static int build_db_impl(const rk_build_desc *d, rk_built_db *out) {

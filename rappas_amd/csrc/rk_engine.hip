@@ -16,6 +16,8 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
+#include <atomic>
 #include <mutex>
 #include <tuple>
 #include <new>
@@ -788,6 +790,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
 }
 
 extern "C" int rk_db_validate(const rk_db_desc *d, rk_db_info *info) {
+    RK_GUARD_BEGIN
     DbImage img;
     int rc = build_image(d, img);
     if (rc) return rc;
@@ -799,9 +802,11 @@ extern "C" int rk_db_validate(const rk_db_desc *d, rk_db_info *info) {
         info->bits_per_symbol = img.bits; info->max_row_len = img.max_len; info->device = -1;
     }
     return RK_OK;
+    RK_GUARD_END("rk_db_validate")
 }
 
 extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
+    RK_GUARD_BEGIN
     if (!d || !out) return fail(RK_ERR_INVALID, "rk_db_create: null argument");
     *out = nullptr;
     DbImage img;
@@ -850,11 +855,13 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     if (rc) { rk_db_destroy(db); return rc; }
     *out = db;
     return RK_OK;
+    RK_GUARD_END("rk_db_create")
 }
 
 // A second handle of the same database on another (or the same) device, copied device to device: the image is not rebuilt and
 // nothing goes back through the host (a C5-class image is 200 GB; xGMI moves it in seconds, the host could not even hold it).
 extern "C" int rk_db_clone(const rk_db *src, int32_t device, rk_db **out) {
+    RK_GUARD_BEGIN
     if (!src || !out) return fail(RK_ERR_INVALID, "rk_db_clone: null argument");
     *out = nullptr;
     int prev = 0;
@@ -898,6 +905,7 @@ extern "C" int rk_db_clone(const rk_db *src, int32_t device, rk_db **out) {
     db->lanes_per_read = src->lanes_per_read;
     *out = db;
     return RK_OK;
+    RK_GUARD_END("rk_db_clone")
 }
 
 extern "C" int rk_db_get_info(const rk_db *db, rk_db_info *info) {
@@ -920,6 +928,7 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
     if (!seq_ascii || !seq_off) return fail(RK_ERR_INVALID, "rk_place_batch_multi: null reads");
     if (!out->n_rows || !out->branch || !out->score || !out->lwr || !out->flags) return fail(RK_ERR_INVALID, "rk_place_batch_multi: null result array");
     const uint32_t K = p->keep_at_most;
+    RK_GUARD_BEGIN
     std::vector<int> codes(n_dbs, RK_OK);
     std::vector<std::string> msgs(n_dbs);
     std::vector<rk_counters> cts(n_dbs);
@@ -943,12 +952,19 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
 #endif
         rk_result r{out->n_rows + lo, out->branch + lo * K, out->score + lo * K, out->lwr + lo * K, out->flags + lo};
         codes[g] = rk_place_batch(dbs[on], p, hi - lo, seq_ascii, seq_off + lo, &r, &cts[g]);
-        if (codes[g] != RK_OK) msgs[g] = rk_last_error();  // the message lives in this thread: hand it over
+        try {
+            if (codes[g] != RK_OK) msgs[g] = rk_last_error();  // the message lives in this thread: hand it over
+        } catch (...) {  // (nothing may leave a thread's function: std::terminate would take the hosting process down)
+        }
+    };
+    struct JoinAll {  // joined on every way out of the scope, a throwing emplace_back included
+        std::vector<std::thread> v;
+        ~JoinAll() { for (std::thread &t : v) if (t.joinable()) t.join(); }
     };
     {
-        std::vector<std::thread> workers;
-        for (uint32_t g = 0; g < n_dbs; g++) workers.emplace_back([&, g]() { run_shard(g, g, true); });
-        for (std::thread &t : workers) t.join();
+        JoinAll workers;
+        workers.v.reserve(n_dbs);
+        for (uint32_t g = 0; g < n_dbs; g++) workers.v.emplace_back([&, g]() { run_shard(g, g, true); });
     }
     // A shard whose device failed (per-GPU failure => shard re-queued on another GPU) is placed again on
     // the handles that did finish, one after the other, each attempt in a fresh host thread; the process is never restarted.
@@ -962,8 +978,10 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
         const int first_code = codes[g];
         for (uint32_t h = 0; h < n_dbs && codes[g] != RK_OK; h++) {
             if (!healthy[h]) continue;
-            std::thread t([&, g, h]() { run_shard(g, h, false); });
-            t.join();
+            {
+                JoinAll one;
+                one.v.emplace_back([&, g, h]() { run_shard(g, h, false); });
+            }
             if (codes[g] == RK_OK) {
                 char buf[256];
                 snprintf(buf, sizeof(buf), "shard %u failed on device %d (%d: %.120s) and was placed on device %d; ", g, dbs[g]->info.device,
@@ -983,6 +1001,7 @@ extern "C" int rk_place_batch_multi(rk_db *const *dbs, uint32_t n_dbs, const rk_
     // success, but the caller can still learn which device dropped out: rk_last_error() carries the note (empty otherwise)
     (void)fail(RK_OK, "%s", note.c_str());
     return RK_OK;
+    RK_GUARD_END("rk_place_batch_multi")
 }
 
 extern "C" void *rk_host_alloc(uint64_t bytes) {
@@ -1449,6 +1468,14 @@ struct HostInput {
     const uint32_t *flags = nullptr;  // [n] or NULL
 };
 
+static rk::PackSpec pack_spec(const Alphabet &A, uint32_t alphabet, uint32_t bits, uint32_t k, uint32_t words_per_read) {
+    rk::PackSpec P;
+    P.table = A.table; P.bits = bits; P.k = k; P.words_per_read = words_per_read;
+    P.pad_char = alphabet == RK_ALPHABET_DNA ? 'A' : 'R';  // state 0 of either alphabet
+    P.force_scalar = rk_knob("RK_PACK_SCALAR") != nullptr;  // developer / test knob
+    return P;
+}
+
 static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const HostInput &in, rk_result *out, rk_counters *counters,
                       const char *who) {
     const bool packed_in = in.packed != nullptr;
@@ -1482,6 +1509,16 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     };
     const bool in_pinned = packed_in ? is_pinned(in.packed) : is_pinned(seq_ascii);
     const bool out_pinned = is_pinned(out->n_rows) && is_pinned(out->branch) && is_pinned(out->score) && is_pinned(out->lwr) && is_pinned(out->flags);
+    // pageable characters are packed on the host (rk_pack_host.cpp) by this call's worker threads; page-locked ones go to the
+    // device as they are (no host work at all) and are packed there
+    const bool host_pack = !packed_in && !in_pinned;
+    Alphabet alpha;
+    if (host_pack) build_alphabet(db->info.alphabet, db->convert_uo != 0, alpha);
+    // host threads of this call: staging / packing on one side, result copies on the other (both only for pageable memory)
+    unsigned n_stage = in_pinned ? 0u : std::max(1u, host_threads(n_reads, 0) * 5 / 8), n_drain = out_pinned ? 0u : std::max(1u, host_threads(n_reads, 0) * 3 / 8);
+    if (const char *e = rk_knob("RK_STAGE_THREADS")) n_stage = (unsigned)std::max(1, atoi(e));   // developer knobs
+    if (const char *e = rk_knob("RK_DRAIN_THREADS")) n_drain = (unsigned)std::max(1, atoi(e));
+    ForkJoin pool(n_stage ? n_stage - 1 : 0);
     auto count_flags = [&](const uint32_t *fl, uint64_t m) {  // per-batch counters, taken chunk by chunk while the flags are cache-hot
         for (uint64_t r = 0; r < m; r++) {
             const uint32_t f = fl[r];
@@ -1492,25 +1529,20 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             if (f & RK_FLAG_AMBIGUOUS) ct.ambiguous++;
         }
     };
-    auto drain = [&](rk_workspace &w) {  // staged results of the workspace's last chunk -> the caller's arrays
+    auto drain = [&](rk_workspace &w, ForkJoin &dpool) {  // staged results of the workspace's last chunk -> the caller's arrays
         if (!w.pending) return;
         const uint64_t a0 = w.pend_r0, m = w.pend_n;
         if (!out_pinned) {
-            // one set of threads for the five arrays, each thread a range of reads (103 bytes per read at K = 7)
-            unsigned hw = std::thread::hardware_concurrency();
-            const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1u, 12u), m / 16384));
-            auto part = [&](uint64_t lo, uint64_t hi) {
-                const uint64_t c = hi - lo;
+            // the drain thread's workers, each a range of reads over the five arrays (103 bytes per read at K = 7)
+            dpool.run([&](unsigned part, unsigned parts) {
+                const uint64_t lo = m * part / parts, c = m * (part + 1) / parts - lo;
+                if (!c) return;
                 memcpy(out->n_rows + a0 + lo, w.h_nrows.as<uint8_t>() + lo, c);
                 memcpy(out->branch + (a0 + lo) * K, w.h_branch.as<uint16_t>() + lo * K, c * K * 2);
                 memcpy(out->score + (a0 + lo) * K, w.h_score.as<float>() + lo * K, c * K * 4);
                 memcpy(out->lwr + (a0 + lo) * K, w.h_lwr.as<double>() + lo * K, c * K * 8);
                 memcpy(out->flags + a0 + lo, w.h_oflags.as<uint32_t>() + lo, c * 4);
-            };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < T; t++) th.emplace_back(part, m * t / T, m * (t + 1) / T);
-            part(0, m / T);
-            for (std::thread &x : th) x.join();
+            });
         }
         count_flags(out->flags + a0, m);
         w.pending = false;
@@ -1536,6 +1568,12 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
     const int device = db->info.device;
     std::thread drainer([&]() {
         (void)hipSetDevice(device);
+        std::unique_ptr<ForkJoin> dpool;
+        try {
+            dpool.reset(new ForkJoin(n_drain ? n_drain - 1 : 0));
+        } catch (...) {  // no worker threads: this thread copies alone
+        }
+        ForkJoin none(0);
         while (true) {
             unsigned wi;
             {
@@ -1556,7 +1594,15 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             } else {
                 bool ok;
                 { std::lock_guard<std::mutex> lk(qm); ok = drain_status == RK_OK; }
-                if (ok) drain(w); else w.pending = false;
+                if (ok) {
+                    try {
+                        drain(w, dpool ? *dpool : none);
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(qm);
+                        if (drain_status == RK_OK) { drain_status = RK_ERR_NOMEM; drain_msg = "out of host memory while moving results"; }
+                        w.pending = false;
+                    }
+                } else w.pending = false;
             }
             t_wait += t1 - t0; t_drain += now() - t1;
             {
@@ -1566,11 +1612,19 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             qcv.notify_all();
         }
     });
+    // the drainer is joined on EVERY way out of this function, an exception thrown by a container or a thread constructor included
+    // (a joinable std::thread that is destroyed calls std::terminate, which would take the hosting JVM down)
+    struct JoinOnExit {
+        std::function<void()> fn;
+        ~JoinOnExit() { if (fn) fn(); }
+    } join_on_exit;
     auto finish = [&]() {  // every submitted chunk drained, the thread joined
+        if (!drainer.joinable()) return;
         { std::lock_guard<std::mutex> lk(qm); closing = true; }
         qcv.notify_all();
         drainer.join();
     };
+    join_on_exit.fn = finish;
     while (r0 < n_reads && status == RK_OK) {
         uint64_t r1 = r0, max_len = 0;
         if (packed_in) {
@@ -1585,12 +1639,6 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         const uint64_t n = r1 - r0;
         if (max_len > 0x7FFFFFFFull / 8) { status = fail(RK_ERR_UNSUPPORTED, "%s: read longer than 2^28 symbols", who); break; }
         const uint32_t wpr = packed_in ? in.wpr : rk_packed_words(db, (uint32_t)max_len);
-        // packed input: the ASCII of the chunk travels only if one of its reads carries the AMBIGUOUS flag (the ambiguity kernel
-        // works on characters); otherwise 38 instead of 150 bytes per 150-bp read cross the link
-        bool need_ascii = !packed_in;
-        if (packed_in && in.flags && seq_ascii && seq_off)
-            for (uint64_t r = r0; r < r1 && !need_ascii; r++) need_ascii = (in.flags[r] & RK_FLAG_AMBIGUOUS) != 0;
-        const uint64_t nbytes = need_ascii ? seq_off[r1] - seq_off[r0] : 0;
         const unsigned wi = chunk_no % NWS;
         rk_workspace &w = db->ws[wi];
         hipStream_t s = w.stream;
@@ -1603,7 +1651,28 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         double t2 = now();
 #define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
 #define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
-        WS_TRY(w.packed.reserve(n * wpr * 4));
+        const size_t pb = n * wpr * 4;
+        // pageable characters (the usual case behind JNI): packed HERE, by the call's worker threads, straight into the page-locked
+        // staging buffer -- 48 instead of 158 bytes per 150-bp read cross the link and no copy of the characters is made
+        uint32_t chunk_flags = 0;
+        if (host_pack) {
+            WS_TRY(w.h_packed.reserve(pb + 8 * n));
+            uint32_t *hp = w.h_packed.as<uint32_t>(), *hl = hp + n * wpr, *hf = hl + n;
+            const rk::PackSpec P = pack_spec(alpha, db->info.alphabet, db->info.bits_per_symbol, db->info.k, wpr);
+            std::atomic<uint32_t> any{0};
+            pool.run([&](unsigned part, unsigned parts) {
+                any.fetch_or(rk::pack_reads_range(P, seq_ascii, seq_off, r0 + n * part / parts, r0 + n * (part + 1) / parts, r0, hp, hl, hf));
+            });
+            chunk_flags = any.load();
+        }
+        // packed input: the ASCII of the chunk travels only if one of its reads carries the AMBIGUOUS flag (the ambiguity kernel
+        // works on characters); otherwise 38 instead of 150 bytes per 150-bp read cross the link
+        bool need_ascii = !packed_in && !host_pack;
+        if (host_pack) need_ascii = (chunk_flags & RK_FLAG_AMBIGUOUS) != 0;
+        if (packed_in && in.flags && seq_ascii && seq_off)
+            for (uint64_t r = r0; r < r1 && !need_ascii; r++) need_ascii = (in.flags[r] & RK_FLAG_AMBIGUOUS) != 0;
+        const uint64_t nbytes = need_ascii ? seq_off[r1] - seq_off[r0] : 0;
+        WS_TRY(w.packed.reserve(pb));
         WS_TRY(w.lens.reserve(n * 4));
         WS_TRY(w.flags.reserve(n * 4));
         WS_TRY(w.nrows.reserve(n));
@@ -1621,20 +1690,34 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
                 if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
             } else if (nbytes) {
                 WS_TRY(w.h_ascii.reserve(nbytes));
-                parallel_copy(w.h_ascii.p, seq_ascii + seq_off[r0], nbytes);
+                const uint8_t *src = seq_ascii + seq_off[r0];
+                uint8_t *dst = w.h_ascii.as<uint8_t>();
+                pool.run([&](unsigned part, unsigned parts) {
+                    const uint64_t a = nbytes * part / parts, b = nbytes * (part + 1) / parts;
+                    if (b > a) memcpy(dst + a, src + a, b - a);
+                });
                 WS_HIP(hipMemcpyAsync(w.ascii.p, w.h_ascii.p, nbytes, hipMemcpyHostToDevice, s));
             }
             WS_HIP(hipMemcpyAsync(w.off.p, w.h_off.p, (n + 1) * 8, hipMemcpyHostToDevice, s));
         }
         double t3 = now();
-        if (packed_in) {
+        if (host_pack) {
+            WS_HIP(hipMemcpyAsync(w.packed.p, w.h_packed.p, pb, hipMemcpyHostToDevice, s));
+            WS_HIP(hipMemcpyAsync(w.lens.p, (char *)w.h_packed.p + pb, n * 4, hipMemcpyHostToDevice, s));
+            WS_HIP(hipMemcpyAsync(w.flags.p, (char *)w.h_packed.p + pb + n * 4, n * 4, hipMemcpyHostToDevice, s));
+        } else if (packed_in) {
             // packed records (+ lengths, flags): straight from page-locked caller memory, else through the staging buffer
-            const size_t pb = n * wpr * 4, lb = in.lens ? n * 4 : 0, fb = in.flags ? n * 4 : 0;
+            const size_t lb = in.lens ? n * 4 : 0, fb = in.flags ? n * 4 : 0;
             if (in_pinned) {
                 WS_HIP(hipMemcpyAsync(w.packed.p, in.packed + r0 * wpr, pb, hipMemcpyHostToDevice, s));
             } else {
                 WS_TRY(w.h_packed.reserve(pb + lb + fb));
-                parallel_copy(w.h_packed.p, in.packed + r0 * wpr, pb);
+                const char *src = (const char *)(in.packed + r0 * wpr);
+                char *dst = (char *)w.h_packed.p;
+                pool.run([&](unsigned part, unsigned parts) {
+                    const size_t a = pb * part / parts, b = pb * (part + 1) / parts;
+                    if (b > a) memcpy(dst + a, src + a, b - a);
+                });
                 WS_HIP(hipMemcpyAsync(w.packed.p, w.h_packed.p, pb, hipMemcpyHostToDevice, s));
             }
             // (lengths and flags are small: pageable copies are fine, but they must not be read after this call returns
@@ -1655,7 +1738,7 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         (void)t3;
         {
             rk_result dres{w.nrows.as<uint8_t>(), w.branch.as<uint16_t>(), w.score.as<float>(), w.lwr.as<double>(), w.oflags.as<uint32_t>()};
-            const uint32_t *d_lens = (!packed_in || in.lens) ? w.lens.as<uint32_t>() : nullptr;
+            const uint32_t *d_lens = (!packed_in || in.lens) ? w.lens.as<uint32_t>() : nullptr;   // (host-packed chunks carry both)
             const uint32_t *d_flags = (!packed_in || in.flags) ? w.flags.as<uint32_t>() : nullptr;
             WS_TRY(rk_place_packed_device(db, p, n, w.packed.as<uint32_t>(), wpr, d_lens, packed_in ? in.fixed_len : 0, d_flags,
                                           need_ascii ? w.ascii.as<uint8_t>() : nullptr, need_ascii ? w.off.as<uint64_t>() : nullptr, &dres, s));
@@ -1714,7 +1797,9 @@ extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, c
     if (n_reads && (!seq_ascii || !seq_off)) return fail(RK_ERR_INVALID, "rk_place_batch: null reads");
     HostInput in;
     in.ascii = seq_ascii; in.off = seq_off;
+    RK_GUARD_BEGIN
     return place_host(db, p, n_reads, in, out, counters, "rk_place_batch");
+    RK_GUARD_END("rk_place_batch")
 }
 
 extern "C" int rk_place_batch_packed(rk_db *db, const rk_params *p, uint64_t n_reads, const uint32_t *packed, uint32_t words_per_read,
@@ -1729,52 +1814,47 @@ extern "C" int rk_place_batch_packed(rk_db *db, const rk_params *p, uint64_t n_r
     if ((seq_ascii == nullptr) != (seq_off == nullptr)) return fail(RK_ERR_INVALID, "rk_place_batch_packed: seq_ascii and seq_off go together");
     HostInput in;
     in.ascii = seq_ascii; in.off = seq_off; in.packed = packed; in.wpr = words_per_read; in.lens = lens; in.fixed_len = fixed_len; in.flags = flags;
+    RK_GUARD_BEGIN
     return place_host(db, p, n_reads, in, out, counters, "rk_place_batch_packed");
+    RK_GUARD_END("rk_place_batch_packed")
 }
 
 // AmbigSequenceKnife.initTables' char -> state part (AmbigSequenceKnife.java:103-130) on the host, for callers that would rather
-// ship 2 / 5 bits per symbol over PCIe than 8: the same records, lengths and flags pack_reads_kernel produces.
+// ship 2 / 5 bits per symbol over PCIe than 8: the same records, lengths and flags pack_reads_kernel produces (rk_pack_host.cpp:
+// AVX2 + BMI2 blocks of 32 symbols where the machine has them, the table-driven loop otherwise).
+static int pack_reads_threads(const rk::PackSpec &P, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off, uint32_t *packed,
+                              uint32_t *lens, uint32_t *flags, uint32_t n_threads) {
+    ForkJoin pool(host_threads(n_reads, n_threads) - 1);
+    pool.run([&](unsigned part, unsigned parts) {
+        rk::pack_reads_range(P, seq_ascii, seq_off, n_reads * part / parts, n_reads * (part + 1) / parts, 0, packed, lens, flags);
+    });
+    return RK_OK;
+}
+
 extern "C" int rk_pack_reads_host(const rk_db *db, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off, uint32_t words_per_read,
                                   uint32_t *packed, uint32_t *lens, uint32_t *flags, uint32_t n_threads) {
     if (!db || !seq_off || !packed || !lens || !flags || words_per_read == 0) return fail(RK_ERR_INVALID, "rk_pack_reads_host: null/zero argument");
     if (n_reads && !seq_ascii && seq_off[n_reads]) return fail(RK_ERR_INVALID, "rk_pack_reads_host: null reads");
+    RK_GUARD_BEGIN
     Alphabet A;
     build_alphabet(db->info.alphabet, db->convert_uo != 0, A);
-    const uint32_t bits = db->info.bits_per_symbol, k = db->info.k;
-    const uint32_t cap_syms = (words_per_read * 32u) / bits;
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned T = n_threads ? n_threads : std::max(1u, std::min(hw ? hw : 1u, 16u));
-    if (n_reads < 4096) T = 1;
-    auto work = [&](uint64_t lo, uint64_t hi) {
-        for (uint64_t r = lo; r < hi; r++) {
-            const uint64_t o0 = seq_off[r], full = seq_off[r + 1] - o0;
-            const uint32_t R = full > cap_syms ? cap_syms : (uint32_t)full;
-            uint32_t fl = 0;
-            if (full > cap_syms) fl |= RK_FLAG_TOO_LONG;
-            if (R < k) fl |= RK_FLAG_TOO_SHORT;
-            uint32_t *rec = packed + r * words_per_read;
-            uint64_t acc = 0;   // bit buffer, flushed 32 bits at a time
-            uint32_t have = 0, w = 0;
-            for (uint32_t i = 0; i < R; i++) {
-                const uint32_t c = A.table[seq_ascii[o0 + i]];
-                uint32_t st = c;
-                if (c == 0xFF) { fl |= RK_FLAG_BAD_CHAR; st = 0; }
-                else if (c & 0x80) { fl |= RK_FLAG_AMBIGUOUS; st = 0; }
-                acc |= (uint64_t)st << have;
-                have += bits;
-                if (have >= 32) { rec[w++] = (uint32_t)acc; acc >>= 32; have -= 32; }
-            }
-            if (w < words_per_read) rec[w++] = (uint32_t)acc;
-            while (w < words_per_read) rec[w++] = 0;
-            lens[r] = R;
-            flags[r] = fl;
-        }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; t++) th.emplace_back(work, n_reads * t / T, n_reads * (t + 1) / T);
-    work(0, n_reads / T);
-    for (std::thread &x : th) x.join();
-    return RK_OK;
+    return pack_reads_threads(pack_spec(A, db->info.alphabet, db->info.bits_per_symbol, db->info.k, words_per_read), n_reads, seq_ascii, seq_off,
+                              packed, lens, flags, n_threads);
+    RK_GUARD_END("rk_pack_reads_host")
+}
+
+// The same without a database handle (and without a GPU): alphabet, --convertUO switch and k are all the packer needs.
+extern "C" int rk_pack_reads(uint32_t alphabet, int convert_uo, uint32_t k, uint64_t n_reads, const uint8_t *seq_ascii, const uint64_t *seq_off,
+                             uint32_t words_per_read, uint32_t *packed, uint32_t *lens, uint32_t *flags, uint32_t n_threads) {
+    if (alphabet != RK_ALPHABET_DNA && alphabet != RK_ALPHABET_AA) return fail(RK_ERR_INVALID, "rk_pack_reads: alphabet must be 4 (DNA) or 20 (amino acids)");
+    if (!seq_off || !packed || !lens || !flags || words_per_read == 0 || k == 0) return fail(RK_ERR_INVALID, "rk_pack_reads: null/zero argument");
+    if (n_reads && !seq_ascii && seq_off[n_reads]) return fail(RK_ERR_INVALID, "rk_pack_reads: null reads");
+    RK_GUARD_BEGIN
+    Alphabet A;
+    build_alphabet(alphabet, convert_uo != 0, A);
+    return pack_reads_threads(pack_spec(A, alphabet, alphabet == RK_ALPHABET_DNA ? 2u : 5u, k, words_per_read), n_reads, seq_ascii, seq_off, packed,
+                              lens, flags, n_threads);
+    RK_GUARD_END("rk_pack_reads")
 }
 
 #include "rk_synth_impl.h"

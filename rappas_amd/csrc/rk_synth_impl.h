@@ -118,6 +118,7 @@ struct DevBufS {
 }  // namespace
 
 extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
+    RK_GUARD_BEGIN
     if (!d || !out) return fail(RK_ERR_INVALID, "rk_db_create_synth: null argument");
     *out = nullptr;
     if (d->alphabet != RK_ALPHABET_DNA && d->alphabet != RK_ALPHABET_AA)
@@ -297,6 +298,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     if (rc) { rk_db_destroy(db); return rc; }
     *out = db;
     return RK_OK;
+    RK_GUARD_END("rk_db_create_synth")
 }
 
 template <int BITS>

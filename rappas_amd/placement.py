@@ -31,6 +31,24 @@ class Placements:
     counters: dict
 
 
+def pack_reads(alphabet, k, seq, seq_off, words_per_read=None, convert_uo=False, threads=0):
+    """rk_pack_reads: the host-side read packer without a database handle (no GPU): ASCII reads -> (packed u32 [n, wpr], lens u32 [n],
+    flags u32 [n]), the records the device packer produces (AmbigSequenceKnife.java:103-130 char -> state)."""
+    lib = _lib.load()
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    n = seq_off.shape[0] - 1
+    bits = 2 if alphabet == _lib.RK_ALPHABET_DNA else 5
+    if words_per_read is None:
+        max_len = int((seq_off[1:] - seq_off[:-1]).max()) if n else 0
+        words_per_read = max(1, (max_len * bits + 31) // 32)
+    packed = np.zeros((n, words_per_read), np.uint32)
+    lens = np.zeros(n, np.uint32)
+    flags = np.zeros(n, np.uint32)
+    _lib.check(lib.rk_pack_reads(alphabet, int(bool(convert_uo)), k, n, _ptr(seq), _ptr(seq_off), words_per_read, _ptr(packed), _ptr(lens), _ptr(flags), threads))
+    return packed, lens, flags
+
+
 def host_alloc(shape, dtype):
     """numpy array in page-locked host memory (rk_host_alloc): buffers the DMA reads / writes directly, no staging copies in
     rk_place_batch / rk_place_batch_packed.  The memory lives until the process ends (tests and the bench allocate a handful)."""
@@ -182,18 +200,22 @@ class PlacementProcess:
         out.counters = {f: getattr(ct, f) for f, _ in rk_counters._fields_}
         return out
 
-    def pack_reads_host(self, seq, seq_off, max_len=None, threads=0):
+    def pack_reads_host(self, seq, seq_off, max_len=None, threads=0, out=None):
         """rk_pack_reads_host: ASCII reads -> (packed u32 [n, wpr], lens u32 [n], flags u32 [n]) on the host, the records the
-        device packer would produce (AmbigSequenceKnife.java:103-130 char -> state)."""
+        device packer would produce (AmbigSequenceKnife.java:103-130 char -> state).  `out` = (packed, lens, flags) to reuse."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
         n = seq_off.shape[0] - 1
         if max_len is None:
             max_len = int((seq_off[1:] - seq_off[:-1]).max()) if n else 0
         wpr = self.db.packed_words(max_len)
-        packed = np.zeros((n, wpr), np.uint32)
-        lens = np.zeros(n, np.uint32)
-        flags = np.zeros(n, np.uint32)
+        if out is not None:
+            packed, lens, flags = out
+            assert packed.shape == (n, wpr) and packed.dtype == np.uint32 and lens.shape == (n,) and flags.shape == (n,)
+        else:
+            packed = np.zeros((n, wpr), np.uint32)
+            lens = np.zeros(n, np.uint32)
+            flags = np.zeros(n, np.uint32)
         _lib.check(self._lib.rk_pack_reads_host(self.db.handle, n, _ptr(seq), _ptr(seq_off), wpr, _ptr(packed), _ptr(lens), _ptr(flags), threads))
         return packed, lens, flags
 

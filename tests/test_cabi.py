@@ -269,3 +269,53 @@ def test_product_library_reads_no_environment_variable():
     assert not {e for e in env_like if not e.startswith((b"RK_ERR", b"RK_FLAG", b"RK_AMB", b"RK_ALPHABET", b"RK_OK"))}, env_like
     src = "".join(open(os.path.join(ROOT, "rappas_amd", "csrc", f)).read() for f in ("rk_engine.hip", "rk_build.hip", "rk_kernels.hip"))
     assert "getenv(" not in src                                   # every knob goes through rk_knob (rk_internal.h)
+
+
+@pytest.mark.parametrize("alphabet,k,length", [(4, 10, 150), (4, 8, 31), (4, 12, 250), (4, 20, 1000), (20, 5, 100), (20, 3, 32), (20, 8, 250), (20, 2, 7)])
+def test_host_packer_equals_the_reference_packer(alphabet, k, length, monkeypatch):
+    """rk_pack_reads (no GPU, no handle): the vector path (AVX2 + BMI2 blocks of 32 symbols) and the table-driven path
+    (RK_PACK_SCALAR on the developer build) both give the records of the numpy reference packer, the reads' lengths and the flags
+    of AmbigSequenceKnife.java:103-130 (ambiguous -> state 0 + AMBIGUOUS, unsupported -> state 0 + BAD_CHAR), for ragged, empty,
+    too-short and too-long reads"""
+    seq, off = synth.make_reads(alphabet, 5000, length, seed=11 + length, amb_rate=0.004, bad_rate=0.02, var_len=length)
+    bits = 2 if alphabet == 4 else 5
+    lens_true = (off[1:] - off[:-1]).astype(np.int64)
+    want, _ = synth.pack_reads_numpy(alphabet, seq, off)
+    letters = synth.DNA_LETTERS if alphabet == 4 else synth.AA_LETTERS
+    plain = np.zeros(256, bool)
+    plain[letters] = True
+    plain[letters + 32] = True
+    if alphabet == 4:
+        plain[[ord("U"), ord("u")]] = True
+    known = plain.copy()
+    known[list(b"NRYSWKMBDHVnryswkmbdhv-." if alphabet == 4 else b"XBZJxbzj*-!")] = True
+    idx = np.repeat(np.arange(len(lens_true)), lens_true)
+    n_unknown = np.bincount(idx, weights=~known[seq], minlength=len(lens_true))
+    n_amb = np.bincount(idx, weights=known[seq] & ~plain[seq], minlength=len(lens_true))
+    for scalar in (False, True):
+        if scalar:
+            monkeypatch.setenv("RK_PACK_SCALAR", "1")
+            monkeypatch.setattr(_lib, "_LIB", _lib.load_dev())
+        packed, lens, flags = ra.pack_reads(alphabet, k, seq, off, threads=3)
+        assert np.array_equal(packed, want), scalar
+        assert np.array_equal(lens, lens_true)
+        assert np.array_equal((flags & ra.RK_FLAG_BAD_CHAR) != 0, n_unknown > 0)
+        assert np.array_equal((flags & ra.RK_FLAG_AMBIGUOUS) != 0, n_amb > 0)
+        assert np.array_equal((flags & ra.RK_FLAG_TOO_SHORT) != 0, lens_true < k)
+        # records one word too short for the longest reads: cut at the record's capacity and flagged
+        wpr = max(1, packed.shape[1] - 1)
+        cap = wpr * 32 // bits
+        p2, l2, f2 = ra.pack_reads(alphabet, k, seq, off, words_per_read=wpr, threads=2)
+        assert np.array_equal(l2, np.minimum(lens_true, cap)) and np.array_equal((f2 & ra.RK_FLAG_TOO_LONG) != 0, lens_true > cap)
+        full = lens_true <= cap
+        assert np.array_equal(p2[full], want[full][:, :wpr])
+
+
+def test_host_packer_follows_the_convertUO_switch():
+    seq = np.frombuffer(b"RHKUOuoC", dtype=np.uint8)
+    off = np.array([0, 8], dtype=np.uint64)
+    _, _, f0 = ra.pack_reads(20, 3, seq, off)
+    p1, _, f1 = ra.pack_reads(20, 3, seq, off, convert_uo=True)
+    assert f0[0] & ra.RK_FLAG_BAD_CHAR and not (f1[0] & ra.RK_FLAG_BAD_CHAR)
+    states = [(int(p1[0, 0]) | int(p1[0, 1]) << 32) >> (5 * i) & 31 for i in range(8)]
+    assert states == [0, 1, 2, 9, 14, 9, 14, 9]       # U -> C (9), O -> L (14): AAStates.java:118-123
