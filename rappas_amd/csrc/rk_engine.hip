@@ -238,37 +238,67 @@ class ForkJoin {
         for (unsigned i = 0; i < workers; i++) th_.emplace_back([this, i]() { loop(i + 1); });
     }
     ~ForkJoin() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1); }
         cv_.notify_all();
         for (std::thread &t : th_) t.join();
     }
     unsigned parts() const { return (unsigned)th_.size() + 1; }
-    void run(const std::function<void(unsigned, unsigned)> &fn) {
+    void run(const std::function<void(unsigned, unsigned)> &fn) {  // the workers and the caller, each one part; returns when all are done
         if (th_.empty()) { fn(0, 1); return; }
-        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; left_ = (unsigned)th_.size(); gen_++; }
-        cv_.notify_all();
+        post(&fn, 0, parts());
         fn(0, parts());
+        wait();
+    }
+    // the workers alone, while the caller does something else; wait() before the next start() / run().  Without workers the
+    // function runs in start().
+    void start(std::function<void(unsigned, unsigned)> fn) {
+        if (th_.empty()) { fn(0, 1); return; }
+        own_ = std::move(fn);
+        post(&own_, 1, (unsigned)th_.size());
+    }
+    void wait() {
+        for (int spin = 0; spin < 4000 && left_.load(std::memory_order_acquire) != 0; spin++) cpu_relax();
+        if (left_.load(std::memory_order_acquire) == 0) return;
         std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&]() { return left_ == 0; });
-        fn_ = nullptr;
+        done_.wait(lk, [&]() { return left_.load() == 0; });
     }
 
   private:
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    void post(const std::function<void(unsigned, unsigned)> *fn, unsigned base, unsigned parts) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = fn; base_ = base; parts_ = parts;
+            left_.store((unsigned)th_.size(), std::memory_order_release);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+    }
+    // A chunk of the host path is staged in well under a millisecond, so a worker that has just finished one job spins for a few
+    // tens of microseconds before it blocks: the next job usually arrives within that time and a futex wake-up costs as much.
     void loop(unsigned me) {
         uint64_t seen = 0;
         while (true) {
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
             const std::function<void(unsigned, unsigned)> *fn;
+            unsigned part, parts;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&]() { return gen_ != seen; });
-                seen = gen_;
+                cv_.wait(lk, [&]() { return gen_.load() != seen; });
+                seen = gen_.load();
                 if (stop_) return;
                 fn = fn_;
+                part = me - base_;
+                parts = parts_;
             }
-            (*fn)(me, parts());
-            {
+            (*fn)(part, parts);
+            if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m_);
-                if (--left_ == 0) done_.notify_all();
+                done_.notify_all();
             }
         }
     }
@@ -276,8 +306,10 @@ class ForkJoin {
     std::mutex m_;
     std::condition_variable cv_, done_;
     const std::function<void(unsigned, unsigned)> *fn_ = nullptr;
-    uint64_t gen_ = 0;
-    unsigned left_ = 0;
+    std::function<void(unsigned, unsigned)> own_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<unsigned> left_{0};
+    unsigned base_ = 0, parts_ = 1;
     bool stop_ = false;
 };
 
@@ -384,7 +416,7 @@ struct rk_db {
     size_t lds_per_cu = 160 * 1024;
     hipStream_t stream = nullptr;      // spare stream
     std::mutex host_mutex;             // rk_place_batch (host path) owns the workspaces below
-    rk_workspace ws[3];                // device buffers + stream per in-flight chunk (grow-only)
+    rk_workspace ws[4];                // device buffers + stream per in-flight chunk (grow-only)
     std::string kernel_name;
 };
 
@@ -1547,21 +1579,21 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         count_flags(out->flags + a0, m);
         w.pending = false;
     };
-    uint64_t r0 = 0;
     unsigned chunk_no = 0;
     int status = RK_OK;
     // developer knob: RK_HOST_TIMING=1 prints where the host thread of this call spent its time (stderr)
     const bool timing = rk_knob("RK_HOST_TIMING") != nullptr;
     double t_wait = 0, t_drain = 0, t_stage = 0, t_enq = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    // Three workspaces in flight.  This thread stages and enqueues chunk c while a second host thread waits for the stream
-    // of the oldest chunk and moves its results into the caller's arrays: staging, the GPU's work and the result copies of
-    // three different chunks overlap (one host thread doing both by turns kept the GPU waiting: 1.6e8 reads/s on C2).
-    constexpr unsigned NWS = 3;
+    // Four workspaces in flight.  The call's worker threads stage chunk c + 1 (pack its characters / copy its records into
+    // page-locked memory) while this thread enqueues chunk c, and a second host thread waits for the stream of the oldest chunk
+    // and moves its results into the caller's arrays: staging, enqueueing, the GPU's work and the result copies of different
+    // chunks overlap (one host thread doing everything by turns kept the GPU waiting: 1.6e8 reads/s on C2).
+    constexpr unsigned NWS = 4;
     std::mutex qm;
     std::condition_variable qcv;
     std::deque<unsigned> submitted;   // workspace indices in submission order
-    bool ws_busy[NWS] = {false, false, false};
+    bool ws_busy[NWS] = {false, false, false, false};
     bool closing = false;
     int drain_status = RK_OK;
     std::string drain_msg;
@@ -1625,53 +1657,112 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         drainer.join();
     };
     join_on_exit.fn = finish;
-    while (r0 < n_reads && status == RK_OK) {
-        uint64_t r1 = r0, max_len = 0;
+    // A chunk's host side (plan + stage) runs one chunk ahead of its device side (enqueue).
+    struct Plan {
+        uint64_t r0 = 0, r1 = 0, n = 0;
+        uint32_t wpr = 0;
+        unsigned wi = 0;
+        size_t pb = 0;
+        bool staged_async = false;
+        std::atomic<uint32_t> flags{0};   // OR of the flags the host packer set
+    };
+    Plan plans[2];
+    auto plan_chunk = [&](Plan &c, uint64_t from, unsigned no) -> int {  // bounds, record width, workspace (waits until it is free)
+        uint64_t r1 = from, max_len = 0;
         if (packed_in) {
-            r1 = std::min(n_reads, r0 + max_chunk_reads);
+            r1 = std::min(n_reads, from + max_chunk_reads);
         } else {
-            while (r1 < n_reads && r1 - r0 < max_chunk_reads && (seq_off[r1 + 1] - seq_off[r0] <= max_chunk_bytes || r1 == r0)) {
+            while (r1 < n_reads && r1 - from < max_chunk_reads && (seq_off[r1 + 1] - seq_off[from] <= max_chunk_bytes || r1 == from)) {
                 uint64_t L = seq_off[r1 + 1] - seq_off[r1];
                 if (L > max_len) max_len = L;
                 r1++;
             }
         }
-        const uint64_t n = r1 - r0;
-        if (max_len > 0x7FFFFFFFull / 8) { status = fail(RK_ERR_UNSUPPORTED, "%s: read longer than 2^28 symbols", who); break; }
-        const uint32_t wpr = packed_in ? in.wpr : rk_packed_words(db, (uint32_t)max_len);
-        const unsigned wi = chunk_no % NWS;
+        if (max_len > 0x7FFFFFFFull / 8) return fail(RK_ERR_UNSUPPORTED, "%s: read longer than 2^28 symbols", who);
+        c.r0 = from; c.r1 = r1; c.n = r1 - from;
+        c.wpr = packed_in ? in.wpr : rk_packed_words(db, (uint32_t)max_len);
+        c.wi = no % NWS;
+        c.pb = c.n * c.wpr * 4;
+        c.staged_async = false;
+        c.flags.store(0);
+        // the workspace was last used four chunks ago: its results must have left the staging buffers before it is overwritten
+        std::unique_lock<std::mutex> lk(qm);
+        qcv.wait(lk, [&]() { return !ws_busy[c.wi]; });
+        if (drain_status != RK_OK) return fail(drain_status, "%s", drain_msg.c_str());
+        return RK_OK;
+    };
+    // host work of a chunk that needs no HIP call: started on the worker threads, joined with pool.wait()
+    auto stage_start = [&](Plan &c) -> int {
+        rk_workspace &w = db->ws[c.wi];
+        const uint64_t n = c.n, c0 = c.r0;
+        if (host_pack) {
+            // pageable characters (the usual case behind JNI): packed HERE, by the call's worker threads, straight into the
+            // page-locked staging buffer -- 48 instead of 158 bytes per 150-bp read cross the link, no copy of the characters
+            int rc = w.h_packed.reserve(c.pb + 8 * n);
+            if (rc) return rc;
+            uint32_t *hp = w.h_packed.as<uint32_t>(), *hl = hp + n * c.wpr, *hf = hl + n;
+            const rk::PackSpec P = pack_spec(alpha, db->info.alphabet, db->info.bits_per_symbol, db->info.k, c.wpr);
+            Plan *pc = &c;
+            pool.start([=](unsigned part, unsigned parts) {
+                pc->flags.fetch_or(rk::pack_reads_range(P, seq_ascii, seq_off, c0 + n * part / parts, c0 + n * (part + 1) / parts, c0, hp, hl, hf));
+            });
+            c.staged_async = true;
+        } else if (packed_in && !in_pinned) {
+            const size_t lb = in.lens ? n * 4 : 0, fb = in.flags ? n * 4 : 0, pb = c.pb;
+            int rc = w.h_packed.reserve(pb + lb + fb);
+            if (rc) return rc;
+            const char *src = (const char *)(in.packed + c0 * c.wpr);
+            char *dst = (char *)w.h_packed.p;
+            pool.start([=](unsigned part, unsigned parts) {
+                const size_t a = pb * part / parts, b = pb * (part + 1) / parts;
+                if (b > a) memcpy(dst + a, src + a, b - a);
+            });
+            c.staged_async = true;
+        }
+        return RK_OK;
+    };
+    unsigned cur = 0;
+    if (n_reads) {
+        status = plan_chunk(plans[0], 0, 0);
+        if (status == RK_OK) status = stage_start(plans[0]);
+    }
+    while (status == RK_OK) {
+        Plan &c = plans[cur];
+        const uint64_t r0 = c.r0, r1 = c.r1, n = c.n;
+        const uint32_t wpr = c.wpr;
+        const unsigned wi = c.wi;
         rk_workspace &w = db->ws[wi];
         hipStream_t s = w.stream;
-        // the workspace was last used three chunks ago: its results must have left the staging buffers before it is overwritten
-        {
-            std::unique_lock<std::mutex> lk(qm);
-            qcv.wait(lk, [&]() { return !ws_busy[wi]; });
-            if (drain_status != RK_OK) { status = fail(drain_status, "%s", drain_msg.c_str()); break; }
-        }
         double t2 = now();
+        if (c.staged_async) pool.wait();
+        t_stage += now() - t2;
+        // the next chunk's host side starts now and runs while this chunk is enqueued
+        Plan &nx = plans[cur ^ 1];
+        const bool more = r1 < n_reads;
 #define WS_TRY(expr) do { int rc_ = (expr); if (rc_ != RK_OK) { status = rc_; goto done; } } while (0)
 #define WS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { status = fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
-        const size_t pb = n * wpr * 4;
-        // pageable characters (the usual case behind JNI): packed HERE, by the call's worker threads, straight into the page-locked
-        // staging buffer -- 48 instead of 158 bytes per 150-bp read cross the link and no copy of the characters is made
-        uint32_t chunk_flags = 0;
-        if (host_pack) {
-            WS_TRY(w.h_packed.reserve(pb + 8 * n));
-            uint32_t *hp = w.h_packed.as<uint32_t>(), *hl = hp + n * wpr, *hf = hl + n;
-            const rk::PackSpec P = pack_spec(alpha, db->info.alphabet, db->info.bits_per_symbol, db->info.k, wpr);
-            std::atomic<uint32_t> any{0};
-            pool.run([&](unsigned part, unsigned parts) {
-                any.fetch_or(rk::pack_reads_range(P, seq_ascii, seq_off, r0 + n * part / parts, r0 + n * (part + 1) / parts, r0, hp, hl, hf));
-            });
-            chunk_flags = any.load();
-        }
+        const size_t pb = c.pb;
         // packed input: the ASCII of the chunk travels only if one of its reads carries the AMBIGUOUS flag (the ambiguity kernel
         // works on characters); otherwise 38 instead of 150 bytes per 150-bp read cross the link
         bool need_ascii = !packed_in && !host_pack;
-        if (host_pack) need_ascii = (chunk_flags & RK_FLAG_AMBIGUOUS) != 0;
+        if (host_pack) need_ascii = (c.flags.load() & RK_FLAG_AMBIGUOUS) != 0;
         if (packed_in && in.flags && seq_ascii && seq_off)
             for (uint64_t r = r0; r < r1 && !need_ascii; r++) need_ascii = (in.flags[r] & RK_FLAG_AMBIGUOUS) != 0;
         const uint64_t nbytes = need_ascii ? seq_off[r1] - seq_off[r0] : 0;
+        if (need_ascii && nbytes && !(!packed_in && in_pinned)) {  // (rare: a chunk with ambiguity codes) its characters, staged by every thread
+            WS_TRY(w.h_ascii.reserve(nbytes));
+            const uint8_t *src = seq_ascii + seq_off[r0];
+            uint8_t *dst = w.h_ascii.as<uint8_t>();
+            pool.run([&](unsigned part, unsigned parts) {
+                const uint64_t a = nbytes * part / parts, b = nbytes * (part + 1) / parts;
+                if (b > a) memcpy(dst + a, src + a, b - a);
+            });
+        }
+        if (more) {
+            WS_TRY(plan_chunk(nx, r1, chunk_no + 1));
+            WS_TRY(stage_start(nx));
+        }
+        t2 = now();
         WS_TRY(w.packed.reserve(pb));
         WS_TRY(w.lens.reserve(n * 4));
         WS_TRY(w.flags.reserve(n * 4));
@@ -1689,18 +1780,10 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             if (!packed_in && in_pinned) {
                 if (nbytes) WS_HIP(hipMemcpyAsync(w.ascii.p, seq_ascii + seq_off[r0], nbytes, hipMemcpyHostToDevice, s));
             } else if (nbytes) {
-                WS_TRY(w.h_ascii.reserve(nbytes));
-                const uint8_t *src = seq_ascii + seq_off[r0];
-                uint8_t *dst = w.h_ascii.as<uint8_t>();
-                pool.run([&](unsigned part, unsigned parts) {
-                    const uint64_t a = nbytes * part / parts, b = nbytes * (part + 1) / parts;
-                    if (b > a) memcpy(dst + a, src + a, b - a);
-                });
                 WS_HIP(hipMemcpyAsync(w.ascii.p, w.h_ascii.p, nbytes, hipMemcpyHostToDevice, s));
             }
             WS_HIP(hipMemcpyAsync(w.off.p, w.h_off.p, (n + 1) * 8, hipMemcpyHostToDevice, s));
         }
-        double t3 = now();
         if (host_pack) {
             WS_HIP(hipMemcpyAsync(w.packed.p, w.h_packed.p, pb, hipMemcpyHostToDevice, s));
             WS_HIP(hipMemcpyAsync(w.lens.p, (char *)w.h_packed.p + pb, n * 4, hipMemcpyHostToDevice, s));
@@ -1708,18 +1791,8 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         } else if (packed_in) {
             // packed records (+ lengths, flags): straight from page-locked caller memory, else through the staging buffer
             const size_t lb = in.lens ? n * 4 : 0, fb = in.flags ? n * 4 : 0;
-            if (in_pinned) {
-                WS_HIP(hipMemcpyAsync(w.packed.p, in.packed + r0 * wpr, pb, hipMemcpyHostToDevice, s));
-            } else {
-                WS_TRY(w.h_packed.reserve(pb + lb + fb));
-                const char *src = (const char *)(in.packed + r0 * wpr);
-                char *dst = (char *)w.h_packed.p;
-                pool.run([&](unsigned part, unsigned parts) {
-                    const size_t a = pb * part / parts, b = pb * (part + 1) / parts;
-                    if (b > a) memcpy(dst + a, src + a, b - a);
-                });
-                WS_HIP(hipMemcpyAsync(w.packed.p, w.h_packed.p, pb, hipMemcpyHostToDevice, s));
-            }
+            if (in_pinned) WS_HIP(hipMemcpyAsync(w.packed.p, in.packed + r0 * wpr, pb, hipMemcpyHostToDevice, s));
+            else WS_HIP(hipMemcpyAsync(w.packed.p, w.h_packed.p, pb, hipMemcpyHostToDevice, s));
             // (lengths and flags are small: pageable copies are fine, but they must not be read after this call returns
             //  -- the staging buffer keeps them when the caller's memory is pageable)
             if (lb) {
@@ -1734,8 +1807,6 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
             WS_TRY(rk_pack_reads_device(db, n, w.ascii.as<uint8_t>(), w.off.as<uint64_t>(), wpr, w.packed.as<uint32_t>(),
                                         w.lens.as<uint32_t>(), w.flags.as<uint32_t>(), s));
         }
-        t_stage += now() - t2;
-        (void)t3;
         {
             rk_result dres{w.nrows.as<uint8_t>(), w.branch.as<uint16_t>(), w.score.as<float>(), w.lwr.as<double>(), w.oflags.as<uint32_t>()};
             const uint32_t *d_lens = (!packed_in || in.lens) ? w.lens.as<uint32_t>() : nullptr;   // (host-packed chunks carry both)
@@ -1771,10 +1842,12 @@ static int place_host(rk_db *db, const rk_params *p, uint64_t n_reads, const Hos
         }
         qcv.notify_all();
         t_enq += now() - t2;
-        r0 = r1;
         chunk_no++;
+        if (!more) break;
+        cur ^= 1;
     }
 done:
+    pool.wait();  // (an error may leave the next chunk's staging running: it reads the caller's arrays)
     finish();
     for (rk_workspace &w : db->ws) {  // (after an error some streams may still hold work of a half-enqueued chunk)
         if (w.stream && status != RK_OK) (void)hipStreamSynchronize(w.stream);
