@@ -81,8 +81,13 @@ struct PlaceArgs {
     u32 s_stride;  // u32 words per read score vector in LDS
     u32 list_cap;  // u64 slots of the per-read hit list in LDS
     u32 n_pass;    // large-tree kernels: branch-range passes per read (1 unless the score vector exceeds one CU's LDS)
-    u32 main_cap, work_cap;  // windowed kernel: u32 slots of the per-read tagged item list / of the per-window work list
+    u32 main_cap, work_cap;  // windowed kernels: u32 slots of the per-read item list / of the per-window work (touched-slot) list
+    u32 only_marked;         // place_packed16w_kernel as the second launch: only tiles whose first read carries RK_FLAG_INTERNAL_DEFERRED
 };
+
+// set by place_packed16s_kernel in the flag word of a tile's first read when the tile is left to place_packed16w_kernel, which
+// overwrites it with the read's real flags; never visible to a caller
+constexpr u32 RK_FLAG_INTERNAL_DEFERRED = 0x80000000u;
 
 __device__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;

@@ -360,23 +360,35 @@ struct WindowPlan {
 // The dense 16-lane geometry keeps eight waves per CU up to 1 116 branches (choose_geometry); beyond that -- and up to the
 // 65 535 branches of the reference -- the tree is cut into windows of <= 1 024 branches, at most 64 of them
 // (6-bit window ids in winspec and in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
+#ifndef RK_WSTREAM_MIN_BRANCHES
+#define RK_WSTREAM_MIN_BRANCHES 8192u
+#endif
+static bool wstream_tree(uint32_t nb) {  // trees whose tiles go to place_packed16s_kernel first
+    if (rk_knob("RK_WSTREAM_ALWAYS")) return true;  // developer / test knob: the sorted-stream kernel on every windowed tree
+    return nb > RK_WSTREAM_MIN_BRANCHES;
+}
 static bool window_plan(uint32_t nb, WindowPlan &wp) {
     if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
-    uint32_t n_win = (nb + 895) / 896;
+    // up to 8 192 branches place_packed16w_kernel is ahead (windows of <= 1 024 branches, as few as possible: it pays per window);
+    // beyond, place_packed16s_kernel (round 3: a window's cost follows what the read touches in it, so more and smaller windows --
+    // about 500 branches -- cost little and leave the LDS to the lists).  At most 64 windows: up to 1 024 branches each on the
+    // largest trees.  T4k / T8k / T20k / T64k (scripts / bench.py), Mreads/s: 164 / 111 / 54 / 20 with the first kernel, 124 / 103 /
+    // 74 / 28 with the second
+    uint32_t n_win = wstream_tree(nb) ? (nb + 511) / 512 : (nb + 895) / 896;
     if (n_win > RK_MAX_WINDOWS) n_win = RK_MAX_WINDOWS;
     wp.n_win = n_win;
     wp.W = ((nb + n_win - 1) / n_win + 3) & ~3u;
     wp.s_stride = wp.W + 4;
     const uint32_t per_group_words = 160 * 1024 / 8 / 4 / 4;  // 1280 u32 words per read = eight waves per CU
-    // the main list has to hold a whole read (C2-like reads: 145 row units on average, 250 at the tail); what is left goes to the
-    // per-window work list, so that a window is normally applied in one accumulate call (each call pays a pipeline fill)
+    // place_packed16w_kernel: the main list has to hold a whole read (C2-like reads: 145 row units on average, 250 at the tail); what
+    // is left goes to the per-window work list, so that a window is normally applied in one accumulate call
     const uint32_t avail = per_group_words - wp.s_stride;
-    // (88 words = the 44 keys the exact select of a window needs as scratch; seven waves per CU with a 256-item main list were
-    // tried for the 16 x 1 000-branch windows: 61 against 71 Mreads/s)
+    // (88 words = the 44 keys the exact select of a window needs as scratch)
     uint32_t work = avail > 256 + 88 ? avail - 256 : 88;
     if (work > 200) work = 200;
     wp.work_cap = work & ~1u;
     wp.main_cap = (avail - wp.work_cap) & ~1u;
+    if (wp.main_cap > 640) wp.main_cap = 640;
     return wp.main_cap >= 160;
 }
 
@@ -1188,6 +1200,62 @@ static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_
 
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     WindowPlan wp = db->wp;
+    const uint64_t n_tiles = (a.n_reads + 3) / 4;
+    if (!n_tiles) return RK_OK;
+    static const bool no_stream = rk_knob("RK_NO_WSTREAM") != nullptr;  // developer knob: place_packed16w_kernel alone (A/B)
+    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wstream_tree(db->info.n_branches);
+    if (sorted_first) {
+        // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched-slot lists.  Seven waves per CU on
+        //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
+        //      its window segments ----
+        PlaceArgs b = a;
+        const uint32_t work_min = 96u;  // scratch of the second pass: 48 candidate keys
+        // touched slots (u16), one list per lane: a C2-like read touches ~1 350 entries over all windows, so a lane sees about
+        // min(W, 1 500 / windows + 50) / 16 first touches per window; twice that, plus the dummy entry (a lane whose list fills up
+        // has the window scanned whole)
+        const uint32_t per_lane = 2 * ((std::min(wp.W, 1500 / wp.n_win + 50) + 15) / 16) + 4;
+        // ring of row loads: eight deep up to 16 windows, four beyond (a window's segment is padded to whole turns of the ring)
+        const uint32_t ring = wp.n_win > 16 ? 4u : 8u;
+        uint32_t work = std::max(std::max(work_min, 64u + 3u * ring), 8 * per_lane);
+        work = (work + 1) & ~1u;
+        // the list: a C2-like read's 145 units (250 at the tail) + the padding of its window segments to the tile's longest
+        const uint32_t need = 200 + (3 + ring / 2) * wp.n_win + 3 * ring;
+        uint32_t budget = 0;
+        for (uint32_t waves : {8u, 7u, 6u, 5u}) {
+            budget = 160 * 1024 / waves / 4 / 4;
+            if (budget >= wp.s_stride + work + need) break;
+        }
+        uint32_t mainc = budget - wp.s_stride - work;
+        if (mainc > 640) mainc = 640;
+        mainc &= ~1u;
+        b.s_stride = wp.s_stride; b.main_cap = mainc; b.work_cap = work; b.list_cap = work / 2; b.only_marked = 0;
+        const size_t lds_wave = (size_t)4 * (b.s_stride + b.main_cap + b.work_cap) * 4;
+        uint32_t waves_cu = (uint32_t)(db->lds_per_cu / lds_wave);
+        if (waves_cu < 1) return fail(RK_ERR_UNSUPPORTED, "internal: windowed geometry does not fit the LDS");
+        if (waves_cu > 8) waves_cu = 8;
+        auto launch = [&](auto kern) -> int {
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+            uint64_t per_cu = 0;
+            if (int rc = resident_blocks(kern, 64, lds_wave, waves_cu, per_cu)) return rc;
+            uint64_t blocks = (uint64_t)db->cu_count * per_cu;
+            if (blocks > n_tiles) blocks = n_tiles;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, b);
+            return RK_OK;
+        };
+        int rc;
+        const bool mono = db->view.mono != 0;
+        if (db->info.bits_per_symbol == 2) {
+            if (ring == 8) rc = mono ? launch(place_packed16s_kernel<2, 8, 9, true>) : launch(place_packed16s_kernel<2, 8, 9, false>);
+            else rc = mono ? launch(place_packed16s_kernel<2, 4, 9, true>) : launch(place_packed16s_kernel<2, 4, 9, false>);
+        } else {
+            if (ring == 8) rc = mono ? launch(place_packed16s_kernel<5, 8, 9, true>) : launch(place_packed16s_kernel<5, 8, 9, false>);
+            else rc = mono ? launch(place_packed16s_kernel<5, 4, 9, true>) : launch(place_packed16s_kernel<5, 4, 9, false>);
+        }
+        if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- place_packed16w_kernel: every tile (records of more than 16 words), or the tiles the first kernel handed over ----
+    a.only_marked = sorted_first ? 1u : 0u;
     // 88 words = the 44 keys the exact select of a window needs as scratch for keep_at_most <= 8 (K + 16 candidates + 16 winners); 96 beyond
     const uint32_t work_min = a.keep_at_most > 8 ? 96u : 88u;
     if (wp.work_cap < work_min) {
@@ -1203,8 +1271,6 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     uint32_t waves_cu = (uint32_t)(db->lds_per_cu / lds_wave);
     if (waves_cu < 1) return fail(RK_ERR_UNSUPPORTED, "internal: windowed geometry does not fit the LDS");
     if (waves_cu > 8) waves_cu = 8;  // two waves per SIMD: the kernel's register budget
-    const uint64_t n_tiles = (a.n_reads + 3) / 4;
-    if (!n_tiles) return RK_OK;
     auto launch = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
         uint64_t per_cu = 0;
@@ -1393,6 +1459,10 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
+        if (wstream_tree(db->info.n_branches) && !rk_knob("RK_NO_WSTREAM"))
+            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
+                     db->info.bits_per_symbol, db->wp.n_win > 16 ? 4 : 8, db->wp.n_win, db->wp.W);
+        else
         snprintf(buf, sizeof(buf), "place_packed16w_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches lds/wave=%zuB main=%u work=%u",
                  db->info.bits_per_symbol, RK_WRING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),
                  db->wp.main_cap, db->wp.work_cap);
@@ -1936,7 +2006,7 @@ extern "C" int rk_pack_reads(uint32_t alphabet, int convert_uo, uint32_t k, uint
 // diagnostic builds only (scripts/stamps.py)
 extern "C" int rk_debug_read_stamps(unsigned long long *out, int n_waves) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rk::rk_stamp_buf), (size_t)n_waves * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rk::rk_stamp_buf), (size_t)n_waves * 16 * sizeof(unsigned long long)));  // (n_waves = 8192 reads both halves)
     return RK_OK;
 }
 #endif

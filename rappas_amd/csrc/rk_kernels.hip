@@ -36,7 +36,7 @@ namespace rk {
 
 #ifdef RK_STAMPS
 // Diagnostic build only (scripts/stamps.py): per-wave cycle sums of the kernel phases. Never compiled into the product.
-__device__ unsigned long long rk_stamp_buf[4096 * 16];
+__device__ unsigned long long rk_stamp_buf[2 * 4096 * 16];  // second half: place_packed16w_kernel launched behind place_packed16s_kernel
 __device__ __forceinline__ unsigned long long rk_now() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -713,15 +713,16 @@ __device__ __forceinline__ void heads_scan(u32 *S, u32 ns, u32 li, u32 slot_base
 // K rounds over the 4 * G stream heads; returns numBest, the rank-r key in lane r (0 beyond numBest), and whether a dropped
 // entry could belong to the answer: K ranks filled -- only if it ties or beats the weakest winner; fewer -- any dropped entry.
 // The rounds run on the order-preserving integer image of the scores (integer max folds into the DPP rotate).
-template <int G>
-__device__ __forceinline__ int heads_rounds_raw(const Heads4 &h, int K, u32 li, u32 gi, u32 &win_o, u32 &win_i, bool &doubt) {
+template <int G, bool FULLQ = false>  // FULLQ: a head's q is the slot itself (streams fed in any order), not its quad
+__device__ __forceinline__ int heads_rounds_raw(const Heads4 &h, int K, u32 li, u32 gi, u32 &win_o, u32 &win_i, bool &doubt, u32 *kth_o = nullptr) {
     constexpr u32 ORD_NEG_INF = 0x007FFFFFu;  // ord_f32(-inf)
     const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     u32 o0[4], o1[4], n0[4], n1[4];  // n = ~slot: the smaller slot wins a max
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         o0[c] = ord_f32(h.s0[c]); o1[c] = ord_f32(h.s1[c]);
-        n0[c] = ~(4u * h.q0[c] + (u32)c); n1[c] = ~(4u * h.q1[c] + (u32)c);
+        n0[c] = FULLQ ? ~h.q0[c] : ~(4u * h.q0[c] + (u32)c);
+        n1[c] = FULLQ ? ~h.q1[c] : ~(4u * h.q1[c] + (u32)c);
     }
     u32 last = ORD_NEG_INF;
     int num = 0;
@@ -748,6 +749,7 @@ __device__ __forceinline__ int heads_rounds_raw(const Heads4 &h, int K, u32 li, 
     const u32 od = max(max(ord_f32(h.dr[0]), ord_f32(h.dr[1])), max(ord_f32(h.dr[2]), ord_f32(h.dr[3])));
     const bool d = (num == K) ? (od >= last) : (od != ORD_NEG_INF);
     doubt = ((__ballot(d) >> (gi * G)) & gmask) != 0;  // group-uniform
+    if (kth_o) *kth_o = (num == K) ? last : ORD_NEG_INF;  // ordered score of the K-th winner (anything counts while fewer than K are found)
     return num;
 }
 // the same for the slot layout of the packed / ASCII kernels (word 0 of S is the scratch slot, branch x lives in word x + 1)
@@ -1508,6 +1510,13 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
     load_tile(wave_global, c_recw, c_R, c_fin, c_have);
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
+        if (a.only_marked) {  // second launch behind place_packed16s_kernel: only the tiles it handed over (their first read's flag word)
+            const u32 mark = a.o_flags[tile * NG] & RK_FLAG_INTERNAL_DEFERRED;
+            if (!__builtin_amdgcn_readfirstlane((int)mark)) {
+                load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
+                continue;
+            }
+        }
         const u64 r = tile * NG + gi;
         const bool have = c_have;
         c_rec = a.packed + (have ? r : 0ull) * wpr;
@@ -1760,6 +1769,444 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
         RK_STAMP(6);  // redo of tiles in doubt
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
         c_recw = n_recw; c_R = n_R; c_fin = n_fin; c_have = n_have;
+        RK_STAMP(7);  // weigh + store
+    }
+#ifdef RK_STAMPS
+    if (lane == 0 && wave_global < 4096)
+        for (int i = 0; i < 16; i++) rk_stamp_buf[(a.only_marked ? 4096 * 16 : 0) + wave_global * 16 + i] = st_[i];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// place_packed16s_kernel (round 3): the windowed kernel whose cost follows the READ, not the tree.
+//
+// place_packed16w_kernel pays per window: a compaction pass over the read's whole item list, a pipeline fill of the accumulate
+// ring and a scan + reset of all win_w slots -- 64 times over on a 65 535-branch tree, for a read that touches ~1 350 entries
+// whatever the tree's size.  Here, for tiles whose reads fit (one probe batch: <= 144 k-mers; no row that spans more than three
+// windows; the sorted list fits):
+//   * emit: the row units of a read are placed straight from the probe registers into ONE list sorted by window, k-mer order
+//     kept inside a window (counts per window by LDS adds, the segments of the tile's four reads padded to a common length so
+//     that window boundaries fall on the same step for the whole wave, then one returning LDS add per row and window in k-mer
+//     order -- LDS operations of a wave execute in program order -- gives every row its place);
+//   * one continuous accumulate stream over that list: the register ring of row loads runs across window boundaries (no pipeline
+//     fill per window), the window filter is applied when an entry's step comes;
+//   * at a first touch (the lane sees the untouched marker) the slot is appended to the read's TOUCHED list; at a window boundary
+//     only those slots are read into the stream heads and reset -- nothing is scanned, nothing is compacted.  (A window that
+//     overflows the touched list is scanned whole.)  Stream heads fed in any slot order keep the slot itself; a value that ties
+//     with a kept one raises the tile's doubt flag like a dropped candidate does, and the tile is redone with the exact select of
+//     every window, as in place_packed16w_kernel.
+// Tiles that do not fit are marked (RK_FLAG_INTERNAL_DEFERRED in their first read's flag word) and placed by
+// place_packed16w_kernel, launched behind this kernel with only_marked set.  Results are identical to the dense kernels'.
+// LDS per read: S[s_stride] | list[main_cap] | touched[work_cap words = 2 * work_cap u16 slots; also the counters of the emit and
+// the scratch of the exact select].
+// ------------------------------------------------------------------------------------------------
+template <int BITS, int U, int PU, bool MONO>
+__global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
+    constexpr int G = 16, NG = 4, TM = TM_COMPACT;
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = threadIdx.x >> 6;
+    const u32 waves_per_block = blockDim.x >> 6;
+    const u32 gi = lane / G, li = lane % G;
+    const u32 wave_words = NG * (a.s_stride + a.main_cap + a.work_cap);
+    u32 *wbase = lds + wave * wave_words;
+    u32 *S = wbase + gi * a.s_stride;
+    u32 *items = wbase + NG * a.s_stride + gi * a.main_cap;
+    u32 *tlw = wbase + NG * (a.s_stride + a.main_cap) + gi * a.work_cap;  // counters (emit) / touched slots (stream) / u64 scratch (exact select)
+    unsigned short *tl = (unsigned short *)tlw;
+    u64 *work64 = (u64 *)tlw;
+    const u32 nb = a.db.n_branches, k = a.db.k;
+    const u32 W = a.db.win_w, NWIN = a.db.n_win;
+    const float T = a.db.T;
+    const int K = (int)a.keep_at_most;
+    const u64 gmask = (1ull << G) - 1;
+    const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
+    const u32 wpr = a.words_per_read;  // <= 16 (the host launches place_packed16w_kernel alone for longer records)
+    const int list_usable = (int)a.main_cap - 3 * U;
+    const int tl_cap = (int)a.work_cap * 2;
+
+    for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
+    wave_lds_fence();
+#ifdef RK_STAMPS
+    unsigned long long st_[16] = {0}, t_ = rk_now();
+#endif
+
+    const u64 n_tiles = (a.n_reads + NG - 1) / NG;
+    const u64 wave_global = (u64)blockIdx.x * waves_per_block + wave;
+    const u64 wave_count = (u64)gridDim.x * waves_per_block;
+
+    auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
+        const u64 r = tile * NG + gi;
+        have = tile < n_tiles && r < a.n_reads;
+        recw = 0; R = 0; fin = 0;
+        if (have) {
+            if (li < wpr) recw = a.packed[r * wpr + li];
+            R = a.lens ? a.lens[r] : a.fixed_len;
+            fin = a.flags_in ? a.flags_in[r] : 0u;
+        }
+    };
+    auto row_scan = [](u32 v) {  // inclusive prefix sum over the 16 lanes of a DPP row
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+        return v;
+    };
+    auto wave_max4 = [](int v) {  // largest value among the wave's four groups (v is group-uniform)
+        int m = __builtin_amdgcn_readlane(v, 0);
+        m = max(m, __builtin_amdgcn_readlane(v, 16));
+        m = max(m, __builtin_amdgcn_readlane(v, 32));
+        return max(m, __builtin_amdgcn_readlane(v, 48));
+    };
+
+    u32 c_recw, c_R, c_fin;
+    bool c_have;
+    load_tile(wave_global, c_recw, c_R, c_fin, c_have);
+
+    for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const u64 r = tile * NG + gi;
+        const bool have = c_have;
+        const u32 fin = c_fin, recw = c_recw;
+        u32 R = c_R;
+        {
+            const u32 cap_syms = (wpr * 32u) / BITS;
+            R = R < cap_syms ? R : cap_syms;
+        }
+        u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
+        const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+        const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+        if (R < k) flags |= RK_FLAG_TOO_SHORT;
+        const u32 Q = (have && !is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;
+        const float QT = (float)(int)Q * T;
+        // the next tile's inputs travel while this one is worked on
+        load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
+        RK_STAMP(0);  // tile setup
+
+        // ---- probe: one batch holds the whole read ----
+        bool defer = __any(Q > (u32)(PU * G));
+        u32 unit[PU], nch[PU], wf[PU], wsp[PU];
+        {
+            u64 code[PU], desc[PU];
+            RawSlot raw[PU];
+            u32 ws[PU];
+            record_codes<BITS, PU>(recw, 0u, li, k, Q, code);
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                raw[u] = lookup_fetch<BITS, TM>(a.db, code[u]);
+                ws[u] = a.db.winspec[(u32)dense_index<BITS>(code[u], k)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const u32 j = (u32)u * G + li;
+                const u64 d = lookup_decode<BITS, TM>(a.db, raw[u], code[u]);
+                desc[u] = j < Q ? d : 0ull;
+                const u32 len = (u32)desc[u] & DESC_LEN_MASK;
+                nch[u] = (len + G - 1) >> 4;
+                unit[u] = (u32)(desc[u] >> DESC_LEN_BITS) >> 4;
+                wf[u] = ws[u] & 63u;
+                wsp[u] = ws[u] >> 6;
+                defer = defer || (nch[u] != 0 && wsp[u] == 3u);  // a row over more than three windows: the other kernel's business
+            }
+        }
+        defer = __any(defer);
+        // ---- units per window and read: tlw[w], w < 64 ----
+        *(uint4 *)(tlw + 4 * li) = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_fence();
+        if (!defer) {
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                if (nch[u]) {
+                    atomicAdd(&tlw[wf[u]], nch[u]);
+                    if (wsp[u] >= 1u) atomicAdd(&tlw[wf[u] + 1u], nch[u]);
+                    if (wsp[u] >= 2u) atomicAdd(&tlw[wf[u] + 2u], nch[u]);
+                }
+            }
+        }
+        wave_lds_fence();
+        // lane t of the wave <-> window t: the common (padded) length of the window's segment, and where it starts
+        u32 seg_len, seg_end;
+        int total;
+        {
+            const u32 *t0 = wbase + NG * (a.s_stride + a.main_cap);
+            const u32 c0 = t0[lane], c1 = t0[a.work_cap + lane], c2 = t0[2 * a.work_cap + lane], c3 = t0[3 * a.work_cap + lane];
+            seg_len = max(max(c0, c1), max(c2, c3));
+            seg_len = (seg_len + (u32)U - 1u) & ~((u32)U - 1u);  // whole turns of the ring: a window starts at ring slot 0
+            u32 incl = row_scan(seg_len);
+            const u32 r0 = (u32)__builtin_amdgcn_readlane((int)incl, 15), r1 = (u32)__builtin_amdgcn_readlane((int)incl, 31),
+                      r2 = (u32)__builtin_amdgcn_readlane((int)incl, 47);
+            incl += gi >= 1 ? r0 : 0u;
+            incl += gi >= 2 ? r1 : 0u;
+            incl += gi >= 3 ? r2 : 0u;
+            seg_end = incl;
+            total = __builtin_amdgcn_readlane((int)incl, 63);
+        }
+        defer = defer || total > list_usable;
+        if (defer) {  // wave-uniform
+#ifdef RK_STAMPS
+            st_[10] += 1;
+#endif
+            if (lane == 0) a.o_flags[tile * NG] = RK_FLAG_INTERNAL_DEFERRED;
+            wave_lds_fence();
+            continue;
+        }
+        const u64 nonempty = __ballot(seg_len != 0u);
+#ifdef RK_STAMPS
+        st_[11] += 1; st_[12] += (unsigned long long)total;
+#endif
+        wave_lds_fence();  // (every lane has read the counters)
+        {   // running place of every window, per read: starts at the segment's start
+            u32 *t0 = wbase + NG * (a.s_stride + a.main_cap);
+            const u32 st = seg_end - seg_len;
+            t0[lane] = st; t0[a.work_cap + lane] = st; t0[2 * a.work_cap + lane] = st; t0[3 * a.work_cap + lane] = st;
+        }
+        for (int i = (int)li; i < total + 3 * U; i += G) items[i] = ITEM_FILLER;
+        wave_lds_fence();
+        // ---- places: one returning add per row and window, in k-mer order (u-major, then the lanes of the group in turn: LDS
+        //      operations of a wave execute in program order).  Every turn has a result register of its own, so that the sixteen
+        //      adds of a slot are issued back to back (one register for all of them made every add wait for the one before);
+        //      the lane then picks its own turn's result ----
+        u32 place[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const bool spans = __any(nch[u] != 0 && wsp[u] != 0u);
+            u32 pl = 0;
+#pragma unroll 1
+            for (u32 tq = 0; tq < (u32)G; tq += 4) {  // four turns at a time: four adds in flight, one wait (sixteen at a time cost 100 registers)
+                u32 got[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    got[j] = 0;
+                    const bool mine = li == tq + (u32)j && nch[u] != 0;
+                    if (mine) got[j] = atomicAdd(&tlw[wf[u]], nch[u]);
+                    if (spans) {  // (rare, wave-uniform: rows that reach into the next window or two are listed there as well, at the same turn)
+                        if (__any(mine && wsp[u] != 0u)) {
+                            u32 p1 = 0, p2 = 0;
+                            if (mine && wsp[u] >= 1u) p1 = atomicAdd(&tlw[wf[u] + 1u], nch[u]);
+                            if (mine && wsp[u] >= 2u) p2 = atomicAdd(&tlw[wf[u] + 2u], nch[u]);
+                            if (mine && wsp[u] >= 1u) for (u32 c = 0; c < nch[u]; c++) items[p1 + c] = (unit[u] + c) << 7;
+                            if (mine && wsp[u] >= 2u) for (u32 c = 0; c < nch[u]; c++) items[p2 + c] = (unit[u] + c) << 7;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) pl = li == tq + (u32)j ? got[j] : pl;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            place[u] = pl;
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            if (nch[u] > 0) items[place[u]] = unit[u] << 7;  // item = byte offset of the 128-byte unit
+            if (nch[u] > 1) items[place[u] + 1u] = (unit[u] + 1u) << 7;
+            for (u32 c = 2; __any(c < nch[u]); c++)
+                if (c < nch[u]) items[place[u] + c] = (unit[u] + c) << 7;
+        }
+        wave_lds_fence();
+        RK_STAMP(1);  // probe + emit + sort
+
+        // ---- the stream ----
+        const u32 li8 = li * 8;
+        auto issue = [&](u32 item, u32 &b, float &v) {
+            const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rows_rs, (int)(item + li8), 0, RK_ROW_AUX);
+            b = e.x;
+            v = __uint_as_float(e.y);
+        };
+        u64 acc_key = 0;
+        bool doubt = false;
+        Heads4 hd;
+        heads_clear(hd);
+        float tie_v = -INFINITY;  // largest score that arrived equal to a kept one of its stream
+        // second pass of a tile in doubt: every entry at or above the K-th score the first pass found is a CANDIDATE (the true K best
+        // are among them, and they are few); a lane keeps up to three, the group's <= 48 are ranked exactly at the end
+        u32 tau_o = 0;
+        u64 cand0 = 0, cand1 = 0, cand2 = 0;  // (a tile is in doubt BECAUSE some lane holds three of the best: two would never do)
+        bool cand_over = false;
+        for (int phase = 0; phase < 2; phase++) {
+            if (phase == 1) {
+                if (!__any(doubt)) break;
+#ifdef RK_STAMPS
+                st_[15] += 1;
+#endif
+                const int num0 = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+                u32 t_o = acc_key != 0ull ? ~(u32)(acc_key >> 32) : 0u;  // smallest ordered score among the winners = largest complement
+                t_o = group_max_u32<G>(t_o);
+                tau_o = num0 >= K ? ~t_o : 0u;  // (fewer than K found: everything is a candidate -- the tile then goes to the other kernel)
+            }
+            // ---- fast pass ----
+            u32 wcur = nonempty ? (u32)__builtin_ctzll(nonempty) : 0u;
+            u64 left = nonempty & (nonempty - 1);
+            int bound = nonempty ? __builtin_amdgcn_readlane((int)seg_end, (int)wcur) : 0x7FFFFFFF;  // first step behind the current window
+            u32 wlo = wcur * W;
+            u32 wlo4p4 = wlo * 4u + 4u, w4 = (nb - wlo < W ? nb - wlo : W) * 4u;
+            // touched slots of the current window: every lane keeps the slots IT saw first in a list of its own (capl entries of
+            // the read's touched region), so that a step needs no ballot and no rank: the slot is written at the lane's count, the
+            // count moves on only at a first touch
+            const int capl = tl_cap / G;
+            unsigned short *tll = tl + li * (u32)capl;
+            int tn = 0;
+            auto finish_window = [&]() {
+                const bool full = __any(tn >= capl);  // some lane's list is full (its last entry is the dummy the non-first steps write)
+                if (full) {  // (wave-uniform) the window is scanned whole, slots as they are
+                    if (phase == 1) cand_over = true;
+                    uint4 *S4 = (uint4 *)S;
+                    const u32 n4 = (w4 / 4u + 1u + 3u) / 4u;
+                    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
+                    if (li == 0) S[0] = S_UNTOUCHED;
+                    wave_lds_fence();
+                    for (u32 q = li; q < n4; q += G) {
+                        const uint4 v4 = S4[q];
+                        S4[q] = reset4;
+                        const u32 s4 = wlo + 4u * q;  // slot id = branch + 1 = wlo + word index
+                        heads_feed<0>(hd, __uint_as_float(v4.x), s4);
+                        heads_feed<1>(hd, __uint_as_float(v4.y), s4 + 1u);
+                        heads_feed<2>(hd, __uint_as_float(v4.z), s4 + 2u);
+                        heads_feed<3>(hd, __uint_as_float(v4.w), s4 + 3u);
+                    }
+                } else {
+                    // a lane's entries go to its four streams in turn, starting with another stream in every window (short lists
+                    // would otherwise all land in stream 0)
+                    const int o0 = (int)(wcur & 3u), o1 = (int)((wcur + 1u) & 3u), o2 = (int)((wcur + 2u) & 3u), o3 = (int)((wcur + 3u) & 3u);
+                    for (int b = 0; __any(b < tn); b += 4) {
+                        u32 sbv[4], val[4];
+                        sbv[0] = b + o0 < tn ? (u32)tll[b + o0] : 0u;
+                        sbv[1] = b + o1 < tn ? (u32)tll[b + o1] : 0u;
+                        sbv[2] = b + o2 < tn ? (u32)tll[b + o2] : 0u;
+                        sbv[3] = b + o3 < tn ? (u32)tll[b + o3] : 0u;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            u32 *ps = (u32 *)((unsigned char *)S + sbv[c]);
+                            val[c] = *ps;
+                            *ps = S_UNTOUCHED;  // (lanes beyond their list reset the scratch word)
+                        }
+                        if (phase == 0) {
+                            const float f0 = sbv[0] ? __uint_as_float(val[0]) : -INFINITY, f1 = sbv[1] ? __uint_as_float(val[1]) : -INFINITY,
+                                        f2 = sbv[2] ? __uint_as_float(val[2]) : -INFINITY, f3 = sbv[3] ? __uint_as_float(val[3]) : -INFINITY;
+                            // equal scores inside one stream: their order is the slots', which the streams here do not keep -> second pass
+                            // (it matters only if that score could be among the K best: decided after the rounds)
+                            tie_v = fmaxf(tie_v, (sbv[0] && (f0 == hd.s0[0] || f0 == hd.s1[0])) ? f0 : -INFINITY);
+                            tie_v = fmaxf(tie_v, (sbv[1] && (f1 == hd.s0[1] || f1 == hd.s1[1])) ? f1 : -INFINITY);
+                            tie_v = fmaxf(tie_v, (sbv[2] && (f2 == hd.s0[2] || f2 == hd.s1[2])) ? f2 : -INFINITY);
+                            tie_v = fmaxf(tie_v, (sbv[3] && (f3 == hd.s0[3] || f3 == hd.s1[3])) ? f3 : -INFINITY);
+                            heads_feed<0>(hd, f0, wlo + (sbv[0] >> 2));
+                            heads_feed<1>(hd, f1, wlo + (sbv[1] >> 2));
+                            heads_feed<2>(hd, f2, wlo + (sbv[2] >> 2));
+                            heads_feed<3>(hd, f3, wlo + (sbv[3] >> 2));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const bool is = sbv[c] != 0u && ord_f32(__uint_as_float(val[c])) >= tau_o;
+                                const u64 key = make_key(val[c], wlo + (sbv[c] >> 2) - 1u);
+                                cand_over = cand_over || (is && cand2 != 0ull);
+                                cand2 = (is && cand1 != 0ull && cand2 == 0ull) ? key : cand2;
+                                cand1 = (is && cand0 != 0ull && cand1 == 0ull) ? key : cand1;
+                                cand0 = (is && cand0 == 0ull) ? key : cand0;
+                            }
+                        }
+                    }
+                }
+                wave_lds_fence();
+                tn = 0;
+                if (left) {
+                    wcur = (u32)__builtin_ctzll(left);
+                    left &= left - 1;
+                    bound = __builtin_amdgcn_readlane((int)seg_end, (int)wcur);
+                    wlo = wcur * W;
+                    wlo4p4 = wlo * 4u + 4u;
+                    w4 = (nb - wlo < W ? nb - wlo : W) * 4u;
+                } else {
+                    bound = 0x7FFFFFFF;
+                    w4 = 0u;  // nothing is inside a window any more: what is left of the ring goes to the scratch word
+                }
+            };
+            auto apply_track = [&](u32 sb_raw, float sc) {
+                const u32 t = sb_raw - wlo4p4;
+                const u32 sbw = (t < w4) ? t + 4u : 0u;
+                u32 *ps = (u32 *)((unsigned char *)S + sbw);
+                const u32 old = *ps;
+                const bool first = old == S_UNTOUCHED && sbw != 0u;
+                float base;
+                if (MONO) asm("v_max_f32 %0, %1, %2" : "=v"(base) : "v"(old), "v"(QT));
+                else base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+                const float d = sc - T;
+                *ps = __float_as_uint(base + d);
+                tll[tn < capl ? tn : capl - 1] = (unsigned short)sbw;  // (kept only if the count moves on)
+                tn += first ? 1 : 0;
+            };
+            u32 sb[U], it[U];
+            float sc[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) issue(items[u], sb[u], sc[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) it[u] = items[U + u];
+            // window by window; the ring runs on across the boundaries (segments are whole turns of it)
+            int s0 = 0;
+            while (bound != 0x7FFFFFFF) {
+                for (; s0 < bound; s0 += U) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        apply_track(sb[u], sc[u]);
+                        issue(it[u], sb[u], sc[u]);
+                        it[u] = items[s0 + 2 * U + u];
+                    }
+                }
+                RK_STAMP(3);  // stream steps
+                finish_window();
+                RK_STAMP(2);  // touched-slot select of the window
+            }
+            // (what is left in the ring are fillers: loads without a memory request)
+            if (phase == 0) {
+                u32 win_o, win_i;
+                bool d0;
+                u32 kth_o;
+                const int num = heads_rounds_raw<G, true>(hd, K, li, gi, win_o, win_i, d0, &kth_o);
+                acc_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
+                const bool tie = tie_v != -INFINITY && ord_f32(tie_v) >= kth_o;
+                doubt = d0 || ((__ballot(tie) >> (gi * G)) & gmask) != 0;
+#ifdef RK_STAMPS
+                st_[13] += __any(d0) ? 1 : 0;   // (diagnostic: tiles in doubt because of a dropped candidate, as against a tie)
+#endif
+                RK_STAMP(5);  // rounds
+            } else {
+                // the group's candidates ranked exactly (keys are unique); more than two in one lane: the other kernel's business
+                work64[li] = cand0;
+                work64[G + li] = cand1;
+                work64[2 * G + li] = cand2;
+                wave_lds_fence();
+                int rank0 = 0, rank1 = 0, rank2 = 0;
+                for (int t = 0; t < 3 * G; t++) {
+                    const u64 o = work64[t];
+                    rank0 += o > cand0 ? 1 : 0;
+                    rank1 += o > cand1 ? 1 : 0;
+                    rank2 += o > cand2 ? 1 : 0;
+                }
+                wave_lds_fence();
+                work64[li] = 0ull;
+                wave_lds_fence();
+                if (cand0 != 0ull && rank0 < K) work64[rank0] = cand0;
+                if (cand1 != 0ull && rank1 < K) work64[rank1] = cand1;
+                if (cand2 != 0ull && rank2 < K) work64[rank2] = cand2;
+                wave_lds_fence();
+                const u64 exact = (int)li < K ? work64[li] : 0ull;
+                wave_lds_fence();
+                // (a group that was not in doubt keeps its first answer: its tau came from K true winners, so both agree -- but its
+                //  candidates may have overflowed without that mattering)
+                const bool mine_doubt = doubt;
+                acc_key = mine_doubt ? exact : acc_key;
+                cand_over = cand_over && mine_doubt;
+            }
+        }
+        if (__any(cand_over)) {  // (wave-uniform) rare twice over: the tile is left to place_packed16w_kernel; S is in its reset state
+            if (lane == 0) a.o_flags[tile * NG] = RK_FLAG_INTERNAL_DEFERRED;
+#ifdef RK_STAMPS
+            st_[10] += 1;
+#endif
+            continue;
+        }
+        const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+        const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+        RK_STAMP(6);  // redo of tiles in doubt
+        if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
         RK_STAMP(7);  // weigh + store
     }
 #ifdef RK_STAMPS

@@ -768,12 +768,42 @@ def test_windowed_kernel_protein_on_large_trees(n_branches):
     sdb = synth.make_db(20, 3, n_branches, 7000, 80000, seed=n_branches)
     odb = O.OracleDB.from_synth(sdb)
     db = ra.PhyloKmerDB.from_synth(sdb)
-    assert "place_packed16w_kernel<BITS=5" in db.kernel_name(), db.kernel_name()
+    assert "place_packed16s_kernel<BITS=5" in db.kernel_name() and "place_packed16w_kernel" in db.kernel_name(), db.kernel_name()
     db.close()
     for length in (90, 240):
         seq, off = synth.make_reads(20, 700, length, seed=length, amb_rate=0.002, bad_rate=0.002, var_len=length // 2)
         for K in (7, 16):
             run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K)
+
+
+@pytest.mark.parametrize("alphabet,k,n_branches,n_keys,n_entries,length", [
+    (4, 8, 1117, 40000, 520000, 150), (4, 8, 2801, 40000, 520000, 150), (4, 8, 3999, 40000, 520000, 150), (4, 8, 7999, 40000, 520000, 150),
+    (4, 8, 15999, 50000, 650000, 160), (4, 8, 40001, 50000, 650000, 150), (4, 8, 65535, 50000, 650000, 150), (4, 7, 9001, 12000, 400000, 120),
+    (20, 3, 3100, 6000, 60000, 90), (20, 3, 20001, 7000, 80000, 100)])
+def test_sorted_stream_kernel_on_every_windowed_tree(alphabet, k, n_branches, n_keys, n_entries, length, monkeypatch, dev_lib):
+    """place_packed16s_kernel (the round-3 windowed kernel: row units sorted by window, one accumulate stream, touched-slot lists)
+    forced onto every windowed tree (it is the default only beyond 8 192 branches), for keep_at_most 1 ... 16, both ambiguity modes,
+    reads with ambiguity codes / unsupported characters / ragged lengths, rows scattered over all windows (tiles it hands over to
+    place_packed16w_kernel), and scores below the threshold (the general first-touch path)"""
+    monkeypatch.setenv("RK_WSTREAM_ALWAYS", "1")
+    sdb = synth.make_db(alphabet, k, n_branches, n_keys, n_entries, seed=n_branches + 1)
+    odb = O.OracleDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_packed16s_kernel" in db.kernel_name(), db.kernel_name()
+    db.close()
+    seq, off = synth.make_reads(alphabet, 3000, length, seed=n_branches, amb_rate=0.001, bad_rate=0.002, var_len=length // 2)
+    for K, amb in ((7, "mean"), (1, "skip"), (3, "max"), (12, "mean"), (16, "skip")):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, amb, keepAtMost=K)
+        assert st["placed"] > 2000
+    import dataclasses
+    sc = sdb.scores.copy()
+    sc[::3] = sc[::3] + np.float32(sdb.thr_log10)
+    low = dataclasses.replace(sdb, scores=sc)
+    run_case(low, O.OracleDB.from_synth(low), seq, off, "direct", 0, "mean")
+    if alphabet == 4:
+        scat = _scatter_rows(synth.make_db(4, 7, n_branches, 12000, 150000, seed=length), seed=n_branches)
+        s2, o2 = synth.make_reads(4, 600, length, seed=3)
+        run_case(scat, O.OracleDB.from_synth(scat), s2, o2, "direct", 0, "mean")
 
 
 def test_dense_rows_on_a_mid_size_tree_take_the_dense_kernels():
