@@ -563,7 +563,11 @@ def main():
         achieved = (B * n_reads / kern_avg_s) / 1e9  # GB/s, algorithmic bytes / average kernel duration
         peak = 8000.0
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration and batch size
+        # (profiles/pmc_traffic_<config>.json, written by scripts/profile.sh + prof_summary.py; null when none matches)
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.config}.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             try:
                 pj = json.load(open(pmc_path))
