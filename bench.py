@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--verify", type=int, default=2000, help="reads checked against the oracle before timing")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clade", action="store_true", help="C2 only: skip the clade-shaped variant of the line (reads cut from a genome whose k-mers "
+                    "make up the database: the K best branches are neighbours, every k-mer is present)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (host buffers through rk_place_batch / rk_place_batch_packed)")
     ap.add_argument("--pcie-reads", type=int, default=4_000_000, help="reads of the PCIe-inclusive leg (rank 0, N=1)")
     ap.add_argument("--db-scale", type=float, default=1.0)
@@ -595,6 +597,37 @@ def main():
             "verified_vs_oracle": verified,
         }
         line.update(per_rank_fields(sync, per_rank))
+        if a.config == "C2" and not a.no_clade and n_gpus == 1:
+            # ---- the same tree and row statistics with clade-shaped reads (what real placements look like): never `value` ----
+            cdb_s, genome = synth.make_clade_db(k=k, n_branches=n_branches)
+            nc = min(2_000_000, n_reads)
+            cseq, coff = synth.make_clade_reads(genome, nc, rlen)
+            cdb = ra.PhyloKmerDB.from_synth(cdb_s, device=local_rank)
+            cpp = ra.PlacementProcess(cdb)
+            cpk = torch.from_numpy(cpp.pack_reads_host(cseq, coff)[0].view(np.int32)).to(dev)
+            cout = cpp.place_packed(cpk, fixed_len=rlen, keepAtMost=K)
+            torch.cuda.synchronize()
+            cH, _ = count_entries_torch(torch, row_length_table(cdb_s), alphabet, k, bits, cpk, rlen)
+            cB = math.ceil(rlen * bits / 8) + Q * 8 + cH / nc * 6 + (2 + K * 14)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                cpp.place_packed(cpk, fixed_len=rlen, out=cout, keepAtMost=K)
+            e1.record()
+            torch.cuda.synchronize()
+            c_s = e0.elapsed_time(e1) / 1e3 / 10
+            nv = min(500, nc)
+            codb = O.OracleDB.from_synth(cdb_s)
+            cgot = ra.Placements(cout["n_rows"][:nv].cpu().numpy(), cout["branch"][:nv].cpu().numpy().view(np.uint16), cout["score"][:nv].cpu().numpy(),
+                                 cout["lwr"][:nv].cpu().numpy(), cout["flags"][:nv].cpu().numpy().view(np.uint32), {})
+            from tests.util import compare_with_oracle as _cmp
+            _cmp(cgot, codb.place(cseq[:int(coff[nv])], coff[:nv + 1], keep_at_most=K), codb, cseq[:int(coff[nv])], coff[:nv + 1])
+            line["clade"] = {"value": nc / c_s, "unit": "reads/s", "kernel_ms": c_s * 1e3, "reads": nc, "entries_per_read": cH / nc, "bytes_per_read": cB,
+                             "roofline_frac": cB * nc / c_s / 1e9 / peak, "verified_vs_oracle": nv,
+                             "workload": f"rappas_amd.synth.make_clade_db: {cdb_s.n_keys} keys / {cdb_s.n_entries} entries on {n_branches} branches, rows of one 500-bp "
+                                         f"stretch of a 700 kbp genome share a neighbourhood of the tree; {nc} x {rlen} bp reads cut from the genome "
+                                         "(every k-mer present: a third more row entries per read than the uniform reads of `value`)"}
+            cdb.close()
         if not a.no_pcie and n_gpus == 1:
             # ---- the boundary RAPPAS would call: host buffers in, host buffers out (never `value`) ----
             # pageable numpy arrays (what a JVM heap array looks like to the library), result arrays allocated once and reused

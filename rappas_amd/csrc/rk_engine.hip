@@ -38,7 +38,7 @@ using namespace rk;
 #define RK_WG_ALWAYS_BRANCHES 65535u  // ... or, whatever the rows, above this many branches (none: the windowed kernel's 64 windows of 1 024 cover every tree)
 #endif
 #ifndef RK_WINDOW_MIN_BRANCHES
-#define RK_WINDOW_MIN_BRANCHES 1116u  // up to here the dense 16-lane geometry keeps eight waves per CU; beyond it the windowed kernel is ahead (scripts/tree_size_sweep.py: 1 300 branches 241 against 219 Mreads/s, 2 800: 185 against 141)
+#define RK_WINDOW_MIN_BRANCHES 1276u  // the dense 16-lane geometry keeps eight waves per CU up to 1 116 branches and seven up to 1 276; the switch sits where the seventh wave goes (round 3, scripts/tree_size_sweep.py, dense against windowed Mreads/s: 1 117 branches 291 / 247, 1 200: 257 / ~245, 1 290 (six waves): 219 / 242, 1 400: 218 / 242, 2 800: 110 / 188)
 #endif
 #ifndef RK_RING
 #define RK_RING 8  // depth of the row-chunk register ring (chunks in flight per lane)
@@ -109,6 +109,13 @@ static int resident_blocks(K kern, int block_threads, size_t lds, uint64_t by_ld
     }
     if (n < 1) return fail(RK_ERR_UNSUPPORTED, "internal: kernel does not fit a CU (%d threads, %zu B of LDS per block)", block_threads, lds);
     out = by_lds < (uint64_t)n ? by_lds : (uint64_t)n;
+    // The LDS is handed out in granules of 512 bytes, which the occupancy query does not count in: 23 232 B per block -- seven by
+    // division and by the query -- are 23 552 B each, and six are resident (round 3, scripts/tree_size_sweep.py at 1 290 branches:
+    // the seventh block of every CU ran in a second round, 140 instead of 250 Mreads/s).
+    if (lds) {
+        const uint64_t by_granule = (160ull * 1024) / ((lds + 511) & ~(size_t)511);
+        if (by_granule >= 1 && by_granule < out) out = by_granule;
+    }
     static const bool trace = rk_knob("RK_TRACE_GRID") != nullptr;  // developer knob
     if (trace) fprintf(stderr, "[rk] grid: %d threads, %zu B LDS per block -> %d resident per CU (by LDS size %llu)\n", block_threads, lds, n, (unsigned long long)by_lds);
     return RK_OK;
@@ -1222,7 +1229,7 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         const uint32_t need = 200 + (3 + ring / 2) * wp.n_win + 3 * ring;
         uint32_t budget = 0;
         for (uint32_t waves : {8u, 7u, 6u, 5u}) {
-            budget = 160 * 1024 / waves / 4 / 4;
+            budget = (160 * 1024 / waves / 512 * 512) / 4 / 4;  // (whole 512-byte granules per wave: see resident_blocks)
             if (budget >= wp.s_stride + work + need) break;
         }
         uint32_t mainc = budget - wp.s_stride - work;

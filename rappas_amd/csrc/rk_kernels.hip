@@ -2521,11 +2521,13 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
             rebase(x);
             const bool have = x != 0xFFFFu;
             const double pw = (have && m.amb_mode == RK_AMB_MEAN) ? exp10((double)v) : 0.0;
+            bool own = false;  // the first alternative that lists x folds it into S (:1161-1172 / :1223-1233)
 #pragma unroll
-            for (u32 ww = 0; ww < 4; ww++) {  // pass 1 (:1139-1157 / :1198-1219)
+            for (u32 ww = 0; ww < 4; ww++) {  // pass 1 (:1139-1157 / :1198-1219): alternative by alternative, in the reference's order
                 if (have && w == ww) {
                     const u32 c = Camb[x];
                     Camb[x] = c + 1;
+                    own = c == 0;
                     if (m.amb_mode == RK_AMB_MEAN) {
                         Samb[x] = (float)((double)Samb[x] + pw);
                     } else {
@@ -2535,22 +2537,15 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 }
                 wave_lds_fence();
             }
-            bool own = false;  // pass 2 (:1161-1172 / :1223-1233): the first alternative that lists x folds it into S
+            // pass 2 in ONE step (round 3; it was one fenced step per alternative): the owners are known from pass 1, and by now
+            // every alternative has left its share in Samb / Camb
             u32 c_own = 0;
             float samb_own = 0.0f;
-#pragma unroll
-            for (u32 ww = 0; ww < 4; ww++) {
-                if (have && w == ww) {
-                    const u32 c = Camb[x];
-                    if (c != 0) {
-                        own = true;
-                        c_own = c;
-                        samb_own = Samb[x];
-                        Camb[x] = 0;
-                        Samb[x] = 0.0f;
-                    }
-                }
-                wave_lds_fence();
+            if (own) {
+                c_own = Camb[x];
+                samb_own = Samb[x];
+                Camb[x] = 0;
+                Samb[x] = 0.0f;
             }
             if (own) {
                 const u32 old = S[x + 1];  // slot layout: branch x is word x + 1
@@ -2581,12 +2576,15 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 if (lane < ((u32)d[w] & DESC_LEN_MASK)) load_entry(a.db, d[w], lane, xb[w], v[w]);
                 rebase(xb[w]);
             }
+            bool owner[4];
 #pragma unroll
             for (int w = 0; w < 4; w++) {  // pass 1 (:1139-1157 / :1198-1219)
+                owner[w] = false;
                 if (xb[w] != 0xFFFFu) {
                     const u32 x = xb[w];
                     const u32 c = Camb[x];
                     Camb[x] = c + 1;
+                    owner[w] = c == 0;  // the first alternative that lists x folds it into S in pass 2
                     if (m.amb_mode == RK_AMB_MEAN) {
                         Samb[x] = (float)((double)Samb[x] + exp10((double)v[w]));
                     } else {
@@ -2597,31 +2595,29 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
                 wave_lds_fence();
             }
 #pragma unroll
-            for (int w = 0; w < 4; w++) {  // pass 2 (:1161-1172 / :1223-1233)
-                if (xb[w] != 0xFFFFu) {
+            for (int w = 0; w < 4; w++) {  // pass 2 (:1161-1172 / :1223-1233), one step: a lane's owned branches are all different
+                if (owner[w]) {
                     const u32 x = xb[w];
                     const u32 c = Camb[x];
-                    if (c != 0) {
-                        const u32 old = S[x + 1];  // slot layout: branch x is word x + 1
-                        const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
-                        float nw;
-                        if (m.amb_mode == RK_AMB_MEAN) {
-                            const float missing = (float)(int)(W - c);
-                            const float pad = missing * P;
-                            const float tot = Samb[x] + pad;
-                            const float avg = tot / (float)(int)W;
-                            nw = (float)((double)base + (log10((double)avg) - (double)T));
-                        } else {
-                            const float dd = Samb[x] - T;
-                            nw = base + dd;
-                        }
-                        S[x + 1] = __float_as_uint(nw);
-                        Camb[x] = 0;
-                        Samb[x] = 0.0f;
+                    const u32 old = S[x + 1];  // slot layout: branch x is word x + 1
+                    const float base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
+                    float nw;
+                    if (m.amb_mode == RK_AMB_MEAN) {
+                        const float missing = (float)(int)(W - c);
+                        const float pad = missing * P;
+                        const float tot = Samb[x] + pad;
+                        const float avg = tot / (float)(int)W;
+                        nw = (float)((double)base + (log10((double)avg) - (double)T));
+                    } else {
+                        const float dd = Samb[x] - T;
+                        nw = base + dd;
                     }
+                    S[x + 1] = __float_as_uint(nw);
+                    Camb[x] = 0;
+                    Samb[x] = 0.0f;
                 }
-                wave_lds_fence();
             }
+            wave_lds_fence();
             return;
         }
     }

@@ -13,35 +13,11 @@ from rappas_amd import synth
 k = 10
 sizes = [int(x) for x in sys.argv[1:]] or [999, 3999, 7999]
 n = 2_000_000
-rng = np.random.default_rng(5)
-glen = 700_000
-g = rng.integers(0, 4, size=glen).astype(np.uint64)
-codes = np.zeros(glen - k + 1, dtype=np.uint64)
-for i in range(k):
-    codes += g[i:glen - k + 1 + i] << np.uint64(2 * i)
-key_codes, first = np.unique(codes, return_index=True)
-order = rng.permutation(len(key_codes))
-key_codes, pos = key_codes[order], first[order]
 for nb in sizes:
-    lens = np.minimum(rng.geometric(1.0 / 12.7, size=len(key_codes)), nb - 1).astype(np.int64)
-    off = np.zeros(len(key_codes) + 1, dtype=np.uint64)
-    np.cumsum(lens, out=off[1:])
-    hi = np.maximum(1, nb - lens)
-    block = pos // 500  # 500-bp stretches of the genome share a neighbourhood of the tree
-    b0 = np.clip(1 + block * np.maximum(1, hi - 40) // (glen // 500 + 1) + rng.integers(-6, 7, size=len(pos)), 1, hi)
-    total = int(off[-1])
-    within = np.arange(total, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
-    branch = (np.repeat(b0, lens) + within).astype(np.uint16)
-    thr, thr_log10 = synth.thresholds(1.5, 4, k)
-    scores = (thr_log10 * rng.random(total, dtype=np.float32)).astype(np.float32)
-    sdb = synth.SynthDB(4, k, nb, thr, thr_log10, key_codes, off, branch, scores, 5)
+    sdb, g = synth.make_clade_db(k=k, n_branches=nb)
     db = ra.PhyloKmerDB.from_synth(sdb)
     pp = ra.PlacementProcess(db)
-    starts = rng.integers(0, glen - 150, size=n)
-    # reads = genome substrings, packed on the host with the engine's packer
-    idx = (starts[:, None] + np.arange(150)[None, :]).reshape(-1)
-    seq = np.frombuffer(b"ATCG", dtype=np.uint8)[g[idx].astype(np.int64)]
-    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(150))
+    seq, offs = synth.make_clade_reads(g, n, 150)  # reads = genome substrings, packed on the host with the engine's packer
     packed, lens_r, flags = pp.pack_reads_host(seq, offs)
     pk = torch.from_numpy(packed.view(np.int32)).cuda()
     out = pp.place_packed(pk, fixed_len=150); torch.cuda.synchronize()

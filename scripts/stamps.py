@@ -10,7 +10,7 @@ branches = int(next((a.split("=")[1] for a in extra if a.startswith("--branches=
 if flags or not os.path.exists(so):  # (prebuild it on the build host into rappas_amd/variants/ to save GPU-box time)
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DRK_DEV_KNOBS", "-DRK_STAMPS"] + flags +
-                   ["-o", so, os.path.join(ROOT, "rappas_amd/csrc/rk_engine.hip")], check=True)
+                   ["-o", so, os.path.join(ROOT, "rappas_amd/csrc/rk_engine.hip"), os.path.join(ROOT, "rappas_amd/csrc/rk_pack_host.cpp")], check=True)
 os.environ["RK_LIB"] = so
 import numpy as np, torch
 import rappas_amd as ra

@@ -610,7 +610,7 @@ def _scatter_rows(sdb, seed):
     return synth.SynthDB(sdb.alphabet, sdb.k, sdb.n_branches, sdb.thr, sdb.thr_log10, sdb.key_codes, sdb.row_offsets, br, sdb.scores, sdb.seed)
 
 
-@pytest.mark.parametrize("n_branches", [1117, 1500, 2801, 3999, 7999, 15999])
+@pytest.mark.parametrize("n_branches", [1291, 1500, 2801, 3999, 7999, 15999])
 @pytest.mark.parametrize("amb", ["mean", "skip"])
 def test_mid_size_trees_take_the_windowed_kernel(n_branches, amb):
     sdb = synth.make_db(4, 8, n_branches, 40000, 520000, seed=n_branches)
@@ -777,7 +777,7 @@ def test_windowed_kernel_protein_on_large_trees(n_branches):
 
 
 @pytest.mark.parametrize("alphabet,k,n_branches,n_keys,n_entries,length", [
-    (4, 8, 1117, 40000, 520000, 150), (4, 8, 2801, 40000, 520000, 150), (4, 8, 3999, 40000, 520000, 150), (4, 8, 7999, 40000, 520000, 150),
+    (4, 8, 1291, 40000, 520000, 150), (4, 8, 2801, 40000, 520000, 150), (4, 8, 3999, 40000, 520000, 150), (4, 8, 7999, 40000, 520000, 150),
     (4, 8, 15999, 50000, 650000, 160), (4, 8, 40001, 50000, 650000, 150), (4, 8, 65535, 50000, 650000, 150), (4, 7, 9001, 12000, 400000, 120),
     (20, 3, 3100, 6000, 60000, 90), (20, 3, 20001, 7000, 80000, 100)])
 def test_sorted_stream_kernel_on_every_windowed_tree(alphabet, k, n_branches, n_keys, n_entries, length, monkeypatch, dev_lib):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_parity_suite_with_64bit_offsets_forced(tmp_path):
     so = str(tmp_path / "librk_off64.so")
     cmd = [build._hipcc()] + [f for f in build.HIPCC_FLAGS] + ["-DRK_FIT32_LIMIT=1000u", "-DRK_DEV_KNOBS", "-o", so,
-                                                               os.path.join(build.CSRC, "rk_engine.hip")]
+                                                               os.path.join(build.CSRC, "rk_engine.hip"), os.path.join(build.CSRC, "rk_pack_host.cpp")]
     subprocess.run(cmd, check=True, cwd=ROOT)
     env = dict(os.environ, RK_LIB=so)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
