@@ -42,9 +42,9 @@ struct ClassDesc {
     std::vector<Field> fields;
     std::shared_ptr<ClassDesc> super;
     std::vector<const ClassDesc *> hierarchy() const {  // super class first, as class data is laid out in the stream
-        std::vector<const ClassDesc *> chain;
-        for (const ClassDesc *d = this; d; d = d->super.get()) chain.insert(chain.begin(), d);
-        return chain;
+        std::vector<const ClassDesc *> chain;  // (finite: Reader::classdesc refuses a chain that comes back to itself)
+        for (const ClassDesc *d = this; d; d = d->super.get()) chain.push_back(d);
+        return std::vector<const ClassDesc *>(chain.rbegin(), chain.rend());
     }
 };
 
@@ -53,17 +53,29 @@ using P = std::shared_ptr<Node>;  // nullptr = Java null
 
 struct Node {
     enum Kind { PRIM, STRING, OBJECT, ARRAY, CLASSDESC, ENUM, BLOCK } kind;
-    char ptype = 0;  // PRIM: B C D F I J S Z
-    int64_t i = 0;   // PRIM integral value (C as its UTF-16 code unit, Z as 0/1)
+    char ptype = 0;  // PRIM: B C D F I J S Z; ARRAY of primitives: the element type
+    int64_t i = 0;   // PRIM integral value (C as its UTF-16 code unit, Z as 0/1); ARRAY of primitives: the element count
     double f = 0;    // PRIM D / F
-    std::string s;   // STRING text, BLOCK bytes, byte[] contents, ENUM constant name
+    std::string s;   // STRING text, BLOCK bytes, ENUM constant name; ARRAY of primitives: the elements as the stream holds them (big-endian)
     std::shared_ptr<ClassDesc> desc;
     std::vector<std::pair<std::string, std::map<std::string, P>>> fields;  // OBJECT: class name -> {field name: value}
     std::vector<std::pair<std::string, std::vector<P>>> annotations;       // OBJECT: class name -> what its writeObject wrote after the fields
-    std::vector<P> elems;                                                  // ARRAY (byte[] keeps its bytes in s instead)
+    std::vector<P> elems;                                                  // ARRAY of objects (primitive arrays stay raw in s: no node per element)
     explicit Node(Kind k) : kind(k) {}
 
     const std::string &classname() const { return desc->name; }
+    static int prim_width(char t) { return t == 'B' || t == 'Z' ? 1 : t == 'C' || t == 'S' ? 2 : t == 'I' || t == 'F' ? 4 : t == 'J' || t == 'D' ? 8 : 0; }
+    // element e of a primitive array as an integer (B S I J signed, C Z unsigned; F / D: their bit pattern)
+    int64_t prim_at(size_t e) const {
+        const int w = prim_width(ptype);
+        if (kind != ARRAY || w == 0 || e >= (size_t)i) throw std::runtime_error("javaser: not an element of a primitive array");
+        uint64_t v = 0;
+        for (int b = 0; b < w; b++) v = v << 8 | (uint8_t)s[e * (size_t)w + (size_t)b];
+        if (ptype == 'B') return (int8_t)v;
+        if (ptype == 'S') return (int16_t)v;
+        if (ptype == 'I') return (int32_t)v;
+        return (int64_t)v;
+    }
     // value of `field` looked up from the most derived class upwards; found = false when no class has it
     P get(const std::string &field, bool *found = nullptr) const {
         for (size_t c = fields.size(); c-- > 0;) {
@@ -124,6 +136,18 @@ class Reader {
     size_t n_, p_ = 0;
     struct Handle { P node; std::shared_ptr<ClassDesc> desc; };
     std::vector<Handle> handles_;
+    // Nesting of content() / classdesc() calls.  ObjectOutputStream itself recurses once per nested object and a JVM's default
+    // stack gives out after a few thousand levels, so no stream a JVM wrote comes near this; a crafted one stops here, not in a
+    // stack overflow (each level costs three or four frames of this reader).
+    static constexpr int MAX_DEPTH = 3000;
+    int depth_ = 0;
+    struct Nest {
+        Reader &r;
+        Nest(Reader &rd, size_t at) : r(rd) {
+            if (++r.depth_ > MAX_DEPTH) { r.depth_--; throw Error("objects nested more than " + std::to_string(MAX_DEPTH) + " deep", at); }
+        }
+        ~Nest() { r.depth_--; }
+    };
 
     const uint8_t *take(size_t n) {
         if (n > n_ - p_) throw Error("truncated stream", p_);
@@ -175,6 +199,7 @@ class Reader {
     // one `object` production
     P content() {
         const size_t at = p_;
+        const Nest nest(*this, at);
         const uint8_t tc = u1();
         switch (tc) {
         case TC_NULL: return nullptr;
@@ -224,12 +249,12 @@ class Reader {
             if (n < 0) throw Error("negative array length", at);
             const char t = a->desc->name.size() > 1 ? a->desc->name[1] : '?';
             if ((size_t)n > n_ - p_) throw Error("array longer than what is left of the stream", at);  // (every element takes >= 1 byte)
-            if (t == 'B') {
-                const uint8_t *raw = take((size_t)n);
-                a->s.assign((const char *)raw, (size_t)n);  // byte[]: kept as bytes (k-mer keys)
-            } else if (is_prim(t)) {
-                a->elems.reserve((size_t)n);
-                for (int32_t e = 0; e < n; e++) a->elems.push_back(prim(t));
+            if (is_prim(t)) {  // kept as the stream's bytes (byte[]: the k-mer keys; char[][]: the alignment), read with prim_at()
+                const size_t bytes = (size_t)n * (size_t)Node::prim_width(t);
+                const uint8_t *raw = take(bytes);
+                a->s.assign((const char *)raw, bytes);
+                a->ptype = t;
+                a->i = n;
             } else {
                 for (int32_t e = 0; e < n; e++) a->elems.push_back(content());
             }
@@ -250,8 +275,17 @@ class Reader {
         }
     }
 
+    // a descriptor's handle exists before its super class is read, so a crafted stream can name the descriptor itself (or one
+    // whose chain leads back to it) as its own super class: refuse it, every walk up the chain relies on it ending
+    void set_super(const std::shared_ptr<ClassDesc> &d, std::shared_ptr<ClassDesc> sup, size_t at) {
+        for (const ClassDesc *c = sup.get(); c; c = c->super.get())
+            if (c == d.get()) throw Error("class descriptor " + d->name + " is its own super class", at);
+        d->super = std::move(sup);
+    }
+
     std::shared_ptr<ClassDesc> classdesc() {
         const size_t at = p_;
+        const Nest nest(*this, at);
         const uint8_t tc = u1();
         if (tc == TC_NULL) return nullptr;
         if (tc == TC_REFERENCE) {
@@ -268,7 +302,7 @@ class Reader {
             const int32_t n = i4();
             for (int32_t e = 0; e < n; e++) utf();
             annotations();
-            d->super = classdesc();
+            set_super(d, classdesc(), at);
             return d;
         }
         if (tc != TC_CLASSDESC) throw Error("type code " + std::to_string(tc) + " where a class descriptor is expected", at);
@@ -285,7 +319,7 @@ class Reader {
             d->fields.push_back({t, std::move(fname)});
         }
         annotations();  // classAnnotation (annotateClass writes nothing by default)
-        d->super = classdesc();
+        set_super(d, classdesc(), at);
         return d;
     }
 

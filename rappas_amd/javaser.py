@@ -136,7 +136,11 @@ class Reader:
                 self.p += 1
                 self.handles = []
             else:
-                yield "object", self.content()
+                at = self.p
+                try:
+                    yield "object", self.content()
+                except RecursionError:  # (rk_javaser.hpp stops at 3000 levels; here the interpreter's own limit does)
+                    raise JavaSerializationError("objects nested too deep", at) from None
 
     def _blockdata(self):
         tc = self._u1()
@@ -204,6 +208,15 @@ class Reader:
             raise JavaSerializationError(f"block data record 0x{tc:02x} where an object is expected", at)
         raise JavaSerializationError(f"unknown type code 0x{tc:02x}", at)
 
+    def _set_super(self, d, sup, at):
+        """a descriptor's handle exists before its super class is read: refuse a chain that comes back to the descriptor"""
+        c = sup
+        while c is not None:
+            if c is d:
+                raise JavaSerializationError(f"class descriptor {d.name} is its own super class", at)
+            c = c.superdesc
+        d.superdesc = sup
+
     def _classdesc(self):
         at = self.p
         tc = self._u1()
@@ -219,7 +232,7 @@ class Reader:
             self._new_handle(d)
             d.interfaces = [self._utf() for _ in range(self._i4())]
             self._annotations()
-            d.superdesc = self._classdesc()
+            self._set_super(d, self._classdesc(), at)
             return d
         if tc != TC_CLASSDESC:
             raise JavaSerializationError(f"type code 0x{tc:02x} where a class descriptor is expected", at)
@@ -234,7 +247,7 @@ class Reader:
             ftype = self.content() if t in "[L" else t  # class name of an object / array field: a String object
             d.fields.append((t, fname, ftype))
         self._annotations()  # classAnnotation (annotateClass writes nothing by default)
-        d.superdesc = self._classdesc()
+        self._set_super(d, self._classdesc(), at)
         return d
 
     def _annotations(self):

@@ -29,6 +29,8 @@ blob = TU.toy_stream()
 open(sys.argv[1] + "/toy.union", "wb").write(blob)
 for cut in range(0, len(blob), 7):  # every seventh truncation of the stream: the reader has to stop with an error, not read past it
     open(sys.argv[1] + f"/cut{cut}.union", "wb").write(blob[:cut])
+for name, h in TU.hostile_streams().items():  # a descriptor that is its own super class, arrays nested 5000 deep
+    open(sys.argv[1] + f"/flip_{name}.union", "wb").write(h)
 import random
 rnd = random.Random(1)
 for i in range(60):  # single-byte corruptions

@@ -154,10 +154,15 @@ def test_union_reader_matches_its_python_twin(rk_place, tmp_path):
 def test_union_reader_rejects_what_is_not_a_union(rk_place, tmp_path):
     from tests import test_uniondb as TU
     good = TU.toy_stream()
-    for name, blob in (("magic", b"\x00\x01\x02\x03" + good[4:]), ("cut", good[:len(good) // 2]), ("empty", b"")):
+    hostile = TU.hostile_streams()  # a descriptor that is its own super class (two shapes), arrays nested 5000 deep
+    for name, blob in (("magic", b"\x00\x01\x02\x03" + good[4:]), ("cut", good[:len(good) // 2]), ("empty", b""), *hostile.items()):
         f = tmp_path / f"{name}.union"
         f.write_bytes(blob)
         r = subprocess.run([rk_place, "--load-uniondb", str(f)], capture_output=True, text=True)
         assert r.returncode == 1 and "rk_place:" in r.stderr, (name, r.stderr)
+        if name in ("own_super", "loop_of_two"):
+            assert "its own super class" in r.stderr
+        if name == "deep":
+            assert "nested more than" in r.stderr
         with pytest.raises(ValueError):
             hostio.load_uniondb(blob)

@@ -104,6 +104,34 @@ def test_errors_carry_the_stream_offset():
         hostio.load_uniondb(data[:4] + data[4:34])  # scalars only: no objects
 
 
+def hostile_streams():
+    """streams no JVM writes: a class descriptor naming itself as its super class, and arrays nested 5000 deep"""
+    head = b"\xac\xed\x00\x05"
+    desc = lambda name: b"\x72" + struct.pack(">H", len(name)) + name + b"\x00" * 8 + b"\x02\x00\x00\x78"  # Serializable, no fields
+    own_super = head + b"\x73" + desc(b"A") + b"\x71\x00\x7e\x00\x00"
+    loop_of_two = head + b"\x73" + desc(b"A") + desc(b"B") + b"\x71\x00\x7e\x00\x00"
+    deep = head + b"\x75" + desc(b"[Ljava.lang.Object;") + b"\x70" + struct.pack(">i", 1) + (b"\x75\x71\x00\x7e\x00\x00" + struct.pack(">i", 1)) * 5000 + b"\x70"
+    return {"own_super": own_super, "loop_of_two": loop_of_two, "deep": deep}
+
+
+def test_hostile_streams_are_refused():
+    h = hostile_streams()
+    for name in ("own_super", "loop_of_two"):
+        with pytest.raises(javaser.JavaSerializationError) as e:
+            javaser.parse(h[name])
+        assert "its own super class" in str(e.value), name
+    with pytest.raises(javaser.JavaSerializationError) as e:
+        javaser.parse(h["deep"])
+    assert "nested too deep" in str(e.value)
+    shallow = hostile_streams.__globals__["struct"].pack(">i", 1)
+    ok = b"\xac\xed\x00\x05\x75\x72\x00\x13[Ljava.lang.Object;" + b"\x00" * 8 + b"\x02\x00\x00\x78\x70" + shallow + (b"\x75\x71\x00\x7e\x00\x00" + shallow) * 50 + b"\x70"
+    (kind, arr), = javaser.parse(ok)
+    depth = 0
+    while arr is not None:
+        arr, depth = arr[0], depth + 1
+    assert kind == "object" and depth == 51
+
+
 def test_union_database_is_accepted_by_the_engine():
     d = hostio.load_uniondb(toy_stream())
     from rappas_amd import placement
