@@ -1212,30 +1212,28 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     static const bool no_stream = rk_knob("RK_NO_WSTREAM") != nullptr;  // developer knob: place_packed16w_kernel alone (A/B)
     const bool sorted_first = a.words_per_read <= 16 && !no_stream && wstream_tree(db->info.n_branches);
     if (sorted_first) {
-        // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched-slot lists.  Seven waves per CU on
+        // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
         //      its window segments ----
         PlaceArgs b = a;
         const uint32_t work_min = 96u;  // scratch of the second pass: 48 candidate keys
-        // touched slots (u16), one list per lane: a C2-like read touches ~1 350 entries over all windows, so a lane sees about
-        // min(W, 1 500 / windows + 50) / 16 first touches per window; twice that, plus the dummy entry (a lane whose list fills up
-        // has the window scanned whole)
-        const uint32_t per_lane = 2 * ((std::min(wp.W, 1500 / wp.n_win + 50) + 15) / 16) + 4;
-        // ring of row loads: eight deep up to 16 windows, four beyond (a window's segment is padded to whole turns of the ring)
-        const uint32_t ring = wp.n_win > 16 ? 4u : 8u;
-        uint32_t work = std::max(std::max(work_min, 64u + 3u * ring), 8 * per_lane);
+        // ring of row loads: eight deep, a window's segment padded to half turns of it (four deep it left the stream waiting
+        // on HBM: ~280 cycles a step; segments padded to whole turns of eight made the largest trees' lists half filler)
+        const uint32_t ring = 8u;
+        uint32_t work = std::max(work_min, 64u + 3u * ring);  // (also: the 64 window counters of the emit, the touched bitmap of the stream)
         work = (work + 1) & ~1u;
         // the list: a C2-like read's 145 units (250 at the tail) + the padding of its window segments to the tile's longest
-        const uint32_t need = 200 + (3 + ring / 2) * wp.n_win + 3 * ring;
+        const uint32_t need = 200 + 5 * wp.n_win + 3 * ring;
+        const uint32_t s_str = wp.W + 16;  // a scratch word per lane in front of the window's slots
         uint32_t budget = 0;
         for (uint32_t waves : {8u, 7u, 6u, 5u}) {
             budget = (160 * 1024 / waves / 512 * 512) / 4 / 4;  // (whole 512-byte granules per wave: see resident_blocks)
-            if (budget >= wp.s_stride + work + need) break;
+            if (budget >= s_str + work + need) break;
         }
-        uint32_t mainc = budget - wp.s_stride - work;
+        uint32_t mainc = budget - s_str - work;
         if (mainc > 640) mainc = 640;
-        mainc &= ~1u;
-        b.s_stride = wp.s_stride; b.main_cap = mainc; b.work_cap = work; b.list_cap = work / 2; b.only_marked = 0;
+        mainc &= ~3u;  // (the list is read four items at a time)
+        b.s_stride = s_str; b.main_cap = mainc; b.work_cap = work; b.list_cap = work / 2; b.only_marked = 0;
         const size_t lds_wave = (size_t)4 * (b.s_stride + b.main_cap + b.work_cap) * 4;
         uint32_t waves_cu = (uint32_t)(db->lds_per_cu / lds_wave);
         if (waves_cu < 1) return fail(RK_ERR_UNSUPPORTED, "internal: windowed geometry does not fit the LDS");
@@ -1250,14 +1248,9 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
             return RK_OK;
         };
         int rc;
-        const bool mono = db->view.mono != 0;
-        if (db->info.bits_per_symbol == 2) {
-            if (ring == 8) rc = mono ? launch(place_packed16s_kernel<2, 8, 9, true>) : launch(place_packed16s_kernel<2, 8, 9, false>);
-            else rc = mono ? launch(place_packed16s_kernel<2, 4, 9, true>) : launch(place_packed16s_kernel<2, 4, 9, false>);
-        } else {
-            if (ring == 8) rc = mono ? launch(place_packed16s_kernel<5, 8, 9, true>) : launch(place_packed16s_kernel<5, 8, 9, false>);
-            else rc = mono ? launch(place_packed16s_kernel<5, 4, 9, true>) : launch(place_packed16s_kernel<5, 4, 9, false>);
-        }
+        const bool wide = wp.W > 512;  // two bitmap words a lane
+        if (db->info.bits_per_symbol == 2) rc = wide ? launch(place_packed16s_kernel<2, 8, 9, true>) : launch(place_packed16s_kernel<2, 8, 9, false>);
+        else rc = wide ? launch(place_packed16s_kernel<5, 8, 9, true>) : launch(place_packed16s_kernel<5, 8, 9, false>);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
     }
@@ -1467,8 +1460,8 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     }
     if (use_windowed(db, 7, 16)) {
         if (wstream_tree(db->info.n_branches) && !rk_knob("RK_NO_WSTREAM"))
-            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
-                     db->info.bits_per_symbol, db->wp.n_win > 16 ? 4 : 8, db->wp.n_win, db->wp.W);
+            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=9,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
+                     db->info.bits_per_symbol, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
         else
         snprintf(buf, sizeof(buf), "place_packed16w_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches lds/wave=%zuB main=%u work=%u",
                  db->info.bits_per_symbol, RK_WRING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),

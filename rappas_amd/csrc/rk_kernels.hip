@@ -18,6 +18,8 @@
 //     K rounds of group arg-max, LWR in fp64 on the first K lanes; the scan also resets S for the next read.
 // No MFMA: this is a gather/accumulate bounded by the memory system, not a contraction.
 #include "rk_device.h"
+
+#include <type_traits>
 #ifndef RK_ROW_NT
 #define RK_ROW_NT 0
 #endif
@@ -1800,9 +1802,9 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
 // LDS per read: S[s_stride] | list[main_cap] | touched[work_cap words = 2 * work_cap u16 slots; also the counters of the emit and
 // the scratch of the exact select].
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int U, int PU, bool MONO>
+template <int BITS, int U, int PU, bool WIDE>
 __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
-    constexpr int G = 16, NG = 4, TM = TM_COMPACT;
+    constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2;
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
@@ -1823,10 +1825,8 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     const u32 wpr = a.words_per_read;  // <= 16 (the host launches place_packed16w_kernel alone for longer records)
     const int list_usable = (int)a.main_cap - 3 * U;
-    const int tl_cap = (int)a.work_cap * 2;
+    u32 *bm = tlw;  // the current window's touched bitmap (words li and, windows over 512 slots, G + li are lane li's)
 
-    for (u32 i = li; i < a.s_stride; i += G) S[i] = S_UNTOUCHED;
-    wave_lds_fence();
 #ifdef RK_STAMPS
     unsigned long long st_[16] = {0}, t_ = rk_now();
 #endif
@@ -1931,7 +1931,7 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
             const u32 *t0 = wbase + NG * (a.s_stride + a.main_cap);
             const u32 c0 = t0[lane], c1 = t0[a.work_cap + lane], c2 = t0[2 * a.work_cap + lane], c3 = t0[3 * a.work_cap + lane];
             seg_len = max(max(c0, c1), max(c2, c3));
-            seg_len = (seg_len + (u32)U - 1u) & ~((u32)U - 1u);  // whole turns of the ring: a window starts at ring slot 0
+            seg_len = (seg_len + (u32)HALF - 1u) & ~((u32)HALF - 1u);  // whole half turns of the ring: a window starts at ring slot 0 or U / 2
             u32 incl = row_scan(seg_len);
             const u32 r0 = (u32)__builtin_amdgcn_readlane((int)incl, 15), r1 = (u32)__builtin_amdgcn_readlane((int)incl, 31),
                       r2 = (u32)__builtin_amdgcn_readlane((int)incl, 47);
@@ -2003,10 +2003,20 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                 if (c < nch[u]) items[place[u] + c] = (unit[u] + c) << 7;
         }
         wave_lds_fence();
+        // the counters have done their work: their first words become the touched bitmap; every slot of S starts from this read's Q * T
+        const u32 QTbits = __float_as_uint(QT);
+        bm[li] = 0u;
+        if (WIDE) bm[G + li] = 0u;
+        {
+            uint4 *S4 = (uint4 *)S;
+            const uint4 q4 = make_uint4(QTbits, QTbits, QTbits, QTbits);
+            for (u32 q = li; q < a.s_stride / 4u; q += G) S4[q] = q4;
+        }
+        wave_lds_fence();
         RK_STAMP(1);  // probe + emit + sort
 
         // ---- the stream ----
-        const u32 li8 = li * 8;
+        const u32 li8 = li * 8, li4 = li * 4;
         auto issue = [&](u32 item, u32 &b, float &v) {
             const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rows_rs, (int)(item + li8), 0, RK_ROW_AUX);
             b = e.x;
@@ -2039,74 +2049,68 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
             int bound = nonempty ? __builtin_amdgcn_readlane((int)seg_end, (int)wcur) : 0x7FFFFFFF;  // first step behind the current window
             u32 wlo = wcur * W;
             u32 wlo4p4 = wlo * 4u + 4u, w4 = (nb - wlo < W ? nb - wlo : W) * 4u;
-            // touched slots of the current window: every lane keeps the slots IT saw first in a list of its own (capl entries of
-            // the read's touched region), so that a step needs no ballot and no rank: the slot is written at the lane's count, the
-            // count moves on only at a first touch
-            const int capl = tl_cap / G;
-            unsigned short *tll = tl + li * (u32)capl;
-            int tn = 0;
+            // Every slot of S holds the read's Q * T (written at the tile's start, restored at a window's end), so a step adds
+            // (score - T) to its slot -- the reference's (Q*T + d1) + d2 ... in k-mer order -- and ORs the slot's bit into the window's
+            // TOUCHED bitmap.  Slot s of the window is bit (s >> 4) of lane (s & 15)'s mask: neighbouring branches fall to different
+            // lanes, and a window's end reads nothing but the touched slots.
             auto finish_window = [&]() {
-                const bool full = __any(tn >= capl);  // some lane's list is full (its last entry is the dummy the non-first steps write)
-                if (full) {  // (wave-uniform) the window is scanned whole, slots as they are
-                    if (phase == 1) cand_over = true;
-                    uint4 *S4 = (uint4 *)S;
-                    const u32 n4 = (w4 / 4u + 1u + 3u) / 4u;
-                    const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
-                    if (li == 0) S[0] = S_UNTOUCHED;
-                    wave_lds_fence();
-                    for (u32 q = li; q < n4; q += G) {
-                        const uint4 v4 = S4[q];
-                        S4[q] = reset4;
-                        const u32 s4 = wlo + 4u * q;  // slot id = branch + 1 = wlo + word index
-                        heads_feed<0>(hd, __uint_as_float(v4.x), s4);
-                        heads_feed<1>(hd, __uint_as_float(v4.y), s4 + 1u);
-                        heads_feed<2>(hd, __uint_as_float(v4.z), s4 + 2u);
-                        heads_feed<3>(hd, __uint_as_float(v4.w), s4 + 3u);
+                typedef typename std::conditional<WIDE, u64, u32>::type mask_t;  // (windows of <= 512 slots: 32 bits a lane)
+                mask_t m = (mask_t)bm[li];
+                bm[li] = 0u;
+                if (WIDE) {
+                    m |= (mask_t)((u64)bm[G + li] << 32);
+                    bm[G + li] = 0u;
+                }
+                // a lane's slots go to its four streams in turn, starting with another stream in every window (short masks would
+                // otherwise all land in stream 0): a rotation by wcur & 3, in two conditional steps
+                const bool r1 = (wcur & 1u) != 0u, r2 = (wcur & 2u) != 0u;
+                const u32 wlom15 = wlo - 15u;
+                while (__any(m != 0)) {
+                    u32 sbt[4], sbv[4], val[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {  // byte offset of the slot in S (below 64 = none: the lane's scratch word)
+                        const u32 bit = WIDE ? (u32)__builtin_ctzll((u64)m) : (u32)__builtin_ctz((u32)m);
+                        sbt[c] = m ? (bit << 6) + li4 + 64u : li4;
+                        m &= m - 1;
                     }
-                } else {
-                    // a lane's entries go to its four streams in turn, starting with another stream in every window (short lists
-                    // would otherwise all land in stream 0)
-                    const int o0 = (int)(wcur & 3u), o1 = (int)((wcur + 1u) & 3u), o2 = (int)((wcur + 2u) & 3u), o3 = (int)((wcur + 3u) & 3u);
-                    for (int b = 0; __any(b < tn); b += 4) {
-                        u32 sbv[4], val[4];
-                        sbv[0] = b + o0 < tn ? (u32)tll[b + o0] : 0u;
-                        sbv[1] = b + o1 < tn ? (u32)tll[b + o1] : 0u;
-                        sbv[2] = b + o2 < tn ? (u32)tll[b + o2] : 0u;
-                        sbv[3] = b + o3 < tn ? (u32)tll[b + o3] : 0u;
+                    {
+                        const u32 a0 = r1 ? sbt[3] : sbt[0], a1 = r1 ? sbt[0] : sbt[1], a2 = r1 ? sbt[1] : sbt[2], a3 = r1 ? sbt[2] : sbt[3];
+                        sbv[0] = r2 ? a2 : a0; sbv[1] = r2 ? a3 : a1; sbv[2] = r2 ? a0 : a2; sbv[3] = r2 ? a1 : a3;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        u32 *ps = (u32 *)((unsigned char *)S + sbv[c]);
+                        val[c] = *ps;
+                        *ps = QTbits;
+                    }
+                    if (phase == 0) {
+                        const bool h0 = sbv[0] >= 64u, h1 = sbv[1] >= 64u, h2 = sbv[2] >= 64u, h3 = sbv[3] >= 64u;
+                        const float f0 = h0 ? __uint_as_float(val[0]) : -INFINITY, f1 = h1 ? __uint_as_float(val[1]) : -INFINITY,
+                                    f2 = h2 ? __uint_as_float(val[2]) : -INFINITY, f3 = h3 ? __uint_as_float(val[3]) : -INFINITY;
+                        // equal scores inside one stream: their order is the slots', which the streams here do not keep -> second pass
+                        // (it matters only if that score could be among the K best: decided after the rounds)
+                        // (a lane without a slot feeds -inf: never equal to a kept score that matters, never kept)
+                        tie_v = fmaxf(tie_v, (f0 == hd.s0[0] || f0 == hd.s1[0]) ? f0 : -INFINITY);
+                        tie_v = fmaxf(tie_v, (f1 == hd.s0[1] || f1 == hd.s1[1]) ? f1 : -INFINITY);
+                        tie_v = fmaxf(tie_v, (f2 == hd.s0[2] || f2 == hd.s1[2]) ? f2 : -INFINITY);
+                        tie_v = fmaxf(tie_v, (f3 == hd.s0[3] || f3 == hd.s1[3]) ? f3 : -INFINITY);
+                        heads_feed<0>(hd, f0, wlom15 + (sbv[0] >> 2));  // slot id = branch + 1
+                        heads_feed<1>(hd, f1, wlom15 + (sbv[1] >> 2));
+                        heads_feed<2>(hd, f2, wlom15 + (sbv[2] >> 2));
+                        heads_feed<3>(hd, f3, wlom15 + (sbv[3] >> 2));
+                    } else {
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            u32 *ps = (u32 *)((unsigned char *)S + sbv[c]);
-                            val[c] = *ps;
-                            *ps = S_UNTOUCHED;  // (lanes beyond their list reset the scratch word)
-                        }
-                        if (phase == 0) {
-                            const float f0 = sbv[0] ? __uint_as_float(val[0]) : -INFINITY, f1 = sbv[1] ? __uint_as_float(val[1]) : -INFINITY,
-                                        f2 = sbv[2] ? __uint_as_float(val[2]) : -INFINITY, f3 = sbv[3] ? __uint_as_float(val[3]) : -INFINITY;
-                            // equal scores inside one stream: their order is the slots', which the streams here do not keep -> second pass
-                            // (it matters only if that score could be among the K best: decided after the rounds)
-                            tie_v = fmaxf(tie_v, (sbv[0] && (f0 == hd.s0[0] || f0 == hd.s1[0])) ? f0 : -INFINITY);
-                            tie_v = fmaxf(tie_v, (sbv[1] && (f1 == hd.s0[1] || f1 == hd.s1[1])) ? f1 : -INFINITY);
-                            tie_v = fmaxf(tie_v, (sbv[2] && (f2 == hd.s0[2] || f2 == hd.s1[2])) ? f2 : -INFINITY);
-                            tie_v = fmaxf(tie_v, (sbv[3] && (f3 == hd.s0[3] || f3 == hd.s1[3])) ? f3 : -INFINITY);
-                            heads_feed<0>(hd, f0, wlo + (sbv[0] >> 2));
-                            heads_feed<1>(hd, f1, wlo + (sbv[1] >> 2));
-                            heads_feed<2>(hd, f2, wlo + (sbv[2] >> 2));
-                            heads_feed<3>(hd, f3, wlo + (sbv[3] >> 2));
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                const bool is = sbv[c] != 0u && ord_f32(__uint_as_float(val[c])) >= tau_o;
-                                const u64 key = make_key(val[c], wlo + (sbv[c] >> 2) - 1u);
-                                cand_over = cand_over || (is && cand2 != 0ull);
-                                cand2 = (is && cand1 != 0ull && cand2 == 0ull) ? key : cand2;
-                                cand1 = (is && cand0 != 0ull && cand1 == 0ull) ? key : cand1;
-                                cand0 = (is && cand0 == 0ull) ? key : cand0;
-                            }
+                            const bool is = sbv[c] >= 64u && ord_f32(__uint_as_float(val[c])) >= tau_o;
+                            const u64 key = make_key(val[c], wlom15 + (sbv[c] >> 2) - 1u);
+                            cand_over = cand_over || (is && cand2 != 0ull);
+                            cand2 = (is && cand1 != 0ull && cand2 == 0ull) ? key : cand2;
+                            cand1 = (is && cand0 != 0ull && cand1 == 0ull) ? key : cand1;
+                            cand0 = (is && cand0 == 0ull) ? key : cand0;
                         }
                     }
                 }
                 wave_lds_fence();
-                tn = 0;
                 if (left) {
                     wcur = (u32)__builtin_ctzll(left);
                     left &= left - 1;
@@ -2116,43 +2120,74 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                     w4 = (nb - wlo < W ? nb - wlo : W) * 4u;
                 } else {
                     bound = 0x7FFFFFFF;
-                    w4 = 0u;  // nothing is inside a window any more: what is left of the ring goes to the scratch word
+                    w4 = 0u;  // nothing is inside a window any more: what is left of the ring is skipped
                 }
             };
+            // A step: read + add + write of the slot (gfx950's LDS float atomic is serialised lane by lane -- ~190 cycles for a wave,
+            // profiles/r03_lds_atomic_rate.txt -- so it is not used), and one non-returning integer OR into the bitmap (full rate).  No
+            // control flow: an entry outside the window -- a filler, or a row that reaches into the next window -- goes through the
+            // lane's own scratch word and ORs nothing, so that the compiler counts the operations in flight exactly.
             auto apply_track = [&](u32 sb_raw, float sc) {
-                const u32 t = sb_raw - wlo4p4;
-                const u32 sbw = (t < w4) ? t + 4u : 0u;
-                u32 *ps = (u32 *)((unsigned char *)S + sbw);
-                const u32 old = *ps;
-                const bool first = old == S_UNTOUCHED && sbw != 0u;
-                float base;
-                if (MONO) asm("v_max_f32 %0, %1, %2" : "=v"(base) : "v"(old), "v"(QT));
-                else base = (old == S_UNTOUCHED) ? QT : __uint_as_float(old);
-                const float d = sc - T;
-                *ps = __float_as_uint(base + d);
-                tll[tn < capl ? tn : capl - 1] = (unsigned short)sbw;  // (kept only if the count moves on)
-                tn += first ? 1 : 0;
+                const u32 t = sb_raw - wlo4p4;  // byte offset of the entry's slot in the window
+                const bool in = t < w4;
+                u32 *ps = (u32 *)((unsigned char *)S + (in ? t + 64u : li4));
+                const float old = __uint_as_float(*ps);
+                *ps = __float_as_uint(old + (sc - T));
+                const u32 sw = t >> 2;
+                const u32 word = WIDE ? ((sw & 15u) | ((sw >> 9) << 4)) : (sw & 15u);
+                __hip_atomic_fetch_or(bm + (in ? word : li), in ? 1u << ((sw >> 4) & 31u) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             };
-            u32 sb[U], it[U];
+            u32 sb[U], it[U];  // it[u]: the item the load of ring slot u is issued with next (read from the list a half turn at a time)
             float sc[U];
+            static_assert(HALF == 4, "items travel four at a time");
+            {
+                const uint4 i0 = *(const uint4 *)(items), i1 = *(const uint4 *)(items + 4), i2 = *(const uint4 *)(items + 8), i3 = *(const uint4 *)(items + 12);
+                // (in ring order, and kept so: the waits of the steps count the loads issued after the one they need)
+                const u32 first[U] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
 #pragma unroll
-            for (int u = 0; u < U; u++) issue(items[u], sb[u], sc[u]);
-#pragma unroll
-            for (int u = 0; u < U; u++) it[u] = items[U + u];
-            // window by window; the ring runs on across the boundaries (segments are whole turns of it)
-            int s0 = 0;
-            while (bound != 0x7FFFFFFF) {
-                for (; s0 < bound; s0 += U) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        apply_track(sb[u], sc[u]);
-                        issue(it[u], sb[u], sc[u]);
-                        it[u] = items[s0 + 2 * U + u];
-                    }
+                for (int u = 0; u < U; u++) {
+                    issue(first[u], sb[u], sc[u]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                RK_STAMP(3);  // stream steps
-                finish_window();
-                RK_STAMP(2);  // touched-slot select of the window
+                it[0] = i2.x; it[1] = i2.y; it[2] = i2.z; it[3] = i2.w;
+                it[4] = i3.x; it[5] = i3.y; it[6] = i3.z; it[7] = i3.w;
+            }
+            // window by window; the ring runs on across the boundaries (segments are whole half turns of it: a window ends after
+            // ring slot U / 2 - 1 or U - 1)
+            int s0 = 0;
+            auto half_turn = [&](auto first) {
+                constexpr int O = decltype(first)::value ? 0 : HALF;
+#pragma unroll
+                for (int u = O; u < O + HALF; u++) {
+                    apply_track(sb[u], sc[u]);
+                    issue(it[u], sb[u], sc[u]);
+                    __builtin_amdgcn_sched_barrier(0);  // (a step waits for ITS load only: without this the scheduler gathers the turn's eight waits into one)
+                }
+                const uint4 nx = *(const uint4 *)(items + s0 + 2 * U);  // (16-byte aligned: the list starts on a 16-byte boundary, s0 is a multiple of 4)
+                it[O] = nx.x; it[O + 1] = nx.y; it[O + 2] = nx.z; it[O + 3] = nx.w;
+                s0 += HALF;
+            };
+            // (two copies of the window's end, so that every path into a step has the ring's loads in flight in the same order:
+            //  with one copy the compiler cannot tell which half a window starts in and waits for ALL loads at every turn)
+            while (bound != 0x7FFFFFFF) {
+                while (s0 + U <= bound) {
+                    half_turn(std::true_type());
+                    half_turn(std::false_type());
+                }
+                if (s0 < bound) {  // the window ends in the middle of a turn: the next one (never empty) starts with the other half
+                    half_turn(std::true_type());
+                    RK_STAMP(3);  // stream steps
+                    finish_window();
+                    asm volatile("; window end, ring at its half turn");  // (two different markers: the copies must not be merged again)
+                    RK_STAMP(2);  // touched-slot select of the window
+                    half_turn(std::false_type());  // (after the last window: four fillers -- an early way out of the loop here would be one
+                                                   //  more path into its head with the ring in another order, and the waits would be for that)
+                } else {
+                    RK_STAMP(3);
+                    finish_window();
+                    asm volatile("; window end, ring at its start");
+                    RK_STAMP(2);
+                }
             }
             // (what is left in the ring are fillers: loads without a memory request)
             if (phase == 0) {
