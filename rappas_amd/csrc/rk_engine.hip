@@ -368,20 +368,22 @@ struct WindowPlan {
 // 65 535 branches of the reference -- the tree is cut into windows of <= 1 024 branches, at most 64 of them
 // (6-bit window ids in winspec and in the item tags), sized so that a wave's four reads fit 20 KB of LDS: 8 waves per CU again.
 #ifndef RK_WSTREAM_MIN_BRANCHES
-#define RK_WSTREAM_MIN_BRANCHES 8192u
+#define RK_WSTREAM_MIN_BRANCHES 4500u
 #endif
-static bool wstream_tree(uint32_t nb) {  // trees whose tiles go to place_packed16s_kernel first
+static bool wstream_tree(uint32_t nb, uint32_t bits) {  // trees whose tiles go to place_packed16s_kernel first
     if (rk_knob("RK_WSTREAM_ALWAYS")) return true;  // developer / test knob: the sorted-stream kernel on every windowed tree
-    return nb > RK_WSTREAM_MIN_BRANCHES;
+    // amino acids: every windowed tree (the first kernel runs with register spills to keep two waves per SIMD: 274 / 248 / 194
+    // Mreads/s at 1 400 / 1 999 / 3 999 branches against 280 / 272 / 241, C4-like rows; profiles/r03_wstream_crossover.txt)
+    return bits == 5 || nb > RK_WSTREAM_MIN_BRANCHES;
 }
-static bool window_plan(uint32_t nb, WindowPlan &wp) {
+static bool window_plan(uint32_t nb, uint32_t bits, WindowPlan &wp) {
     if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
-    // up to 8 192 branches place_packed16w_kernel is ahead (windows of <= 1 024 branches, as few as possible: it pays per window);
+    // up to ~4 500 branches place_packed16w_kernel is ahead (windows of <= 1 024 branches, as few as possible: it pays per window);
     // beyond, place_packed16s_kernel (round 3: a window's cost follows what the read touches in it, so more and smaller windows --
-    // about 500 branches -- cost little and leave the LDS to the lists).  At most 64 windows: up to 1 024 branches each on the
-    // largest trees.  T4k / T8k / T20k / T64k (scripts / bench.py), Mreads/s: 164 / 111 / 54 / 20 with the first kernel, 124 / 103 /
-    // 74 / 28 with the second
-    uint32_t n_win = wstream_tree(nb) ? (nb + 511) / 512 : (nb + 895) / 896;
+    // about 500 branches, one bitmap word a lane -- cost little and leave the LDS to the list).  At most 64 windows: up to 1 024
+    // branches each on the largest trees.  scripts/wstream_crossover.py, Mreads/s at 3 999 / 4 999 / 5 999 / 7 999 branches:
+    // 164 / 147 / 132 / 113 with the first kernel, 159 / 150 / 144 / 135 with the second (profiles/r03_wstream_crossover.txt)
+    uint32_t n_win = wstream_tree(nb, bits) ? (nb + 511) / 512 : (nb + 895) / 896;
     if (n_win > RK_MAX_WINDOWS) n_win = RK_MAX_WINDOWS;
     wp.n_win = n_win;
     wp.W = ((nb + n_win - 1) / n_win + 3) & ~3u;
@@ -407,10 +409,10 @@ static bool window_plan(uint32_t nb, WindowPlan &wp) {
 //     ~39 000);
 //   the plain slot-offset image of the dense kernels otherwise.
 struct ImageKind { bool indexed, windowable; };
-static ImageKind image_kind(uint32_t nb, uint32_t table_mode, uint64_t space, bool space_ok, uint64_t slot_units, uint32_t max_len, double mean_len) {
+static ImageKind image_kind(uint32_t nb, uint32_t bits, uint32_t table_mode, uint64_t space, bool space_ok, uint64_t slot_units, uint32_t max_len, double mean_len) {
     WindowPlan wp;
     const bool direct = table_mode == RK_TABLE_DIRECT || (table_mode == RK_TABLE_AUTO && space_ok && space <= (1ull << 28));
-    const bool windowable = window_plan(nb, wp) && direct && (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB &&
+    const bool windowable = window_plan(nb, bits, wp) && direct && (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB &&
                             windows_pay(nb, slot_units, space);
     const bool long_rows = mean_len >= RK_WG_MIN_MEAN_ROW;
     const bool indexed = nb > RK_WG_MIN_BRANCHES && (long_rows || (!windowable && nb > 16000u));
@@ -704,12 +706,12 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
         slot_units += (len + ROW_UNIT - 1) / ROW_UNIT;
         if (len > longest) longest = (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len);
     }
-    const ImageKind kind = image_kind(d->n_branches, d->table_mode, space, space_ok, slot_units, longest, mean_len);
+    const ImageKind kind = image_kind(d->n_branches, bits, d->table_mode, space, space_ok, slot_units, longest, mean_len);
     const bool indexed = kind.indexed;
     img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
     WindowPlan wp;
-    const bool want_windows = kind.windowable && window_plan(d->n_branches, wp);
+    const bool want_windows = kind.windowable && window_plan(d->n_branches, bits, wp);
     std::vector<unsigned char> ws_by_key;  // winspec_byte(first window, last window) of every row
     if (want_windows) {
         try { ws_by_key.assign(n_keys, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
@@ -1210,7 +1212,7 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     const uint64_t n_tiles = (a.n_reads + 3) / 4;
     if (!n_tiles) return RK_OK;
     static const bool no_stream = rk_knob("RK_NO_WSTREAM") != nullptr;  // developer knob: place_packed16w_kernel alone (A/B)
-    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wstream_tree(db->info.n_branches);
+    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wstream_tree(db->info.n_branches, db->info.bits_per_symbol);
     if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
@@ -1459,7 +1461,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
-        if (wstream_tree(db->info.n_branches) && !rk_knob("RK_NO_WSTREAM"))
+        if (wstream_tree(db->info.n_branches, db->info.bits_per_symbol) && !rk_knob("RK_NO_WSTREAM"))
             snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=9,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
                      db->info.bits_per_symbol, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
         else

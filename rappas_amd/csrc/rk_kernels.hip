@@ -1413,7 +1413,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // Reads whose items do not fit the main list fall back to probing the read once per window (row descriptors + row cursor).
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int U, int PU>
-__global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16w_kernel(PlaceArgs a) {  // (amino acids: 286 registers left to itself = one wave per SIMD; DNA: 219, and slower when asked for two)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT;
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
@@ -1803,7 +1803,7 @@ __global__ void __launch_bounds__(256) place_packed16w_kernel(PlaceArgs a) {
 // the scratch of the exact select].
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int U, int PU, bool WIDE>
-__global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16s_kernel(PlaceArgs a) {  // (amino acids: 264 registers left to itself, one wave per SIMD)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2;
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
@@ -1884,7 +1884,10 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
 
         // ---- probe: one batch holds the whole read ----
         bool defer = __any(Q > (u32)(PU * G));
-        u32 unit[PU], nch[PU], wf[PU], wsp[PU];
+        u32 unit[PU], pk[PU];  // pk: row units (bits 0-15) | first window (16-21) | further windows the row reaches into (22-23)
+        auto NCH = [&](int u) { return pk[u] & 0xFFFFu; };
+        auto WF = [&](int u) { return (pk[u] >> 16) & 63u; };
+        auto WSP = [&](int u) { return pk[u] >> 22; };
         {
             u64 code[PU], desc[PU];
             RawSlot raw[PU];
@@ -1902,11 +1905,10 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                 const u64 d = lookup_decode<BITS, TM>(a.db, raw[u], code[u]);
                 desc[u] = j < Q ? d : 0ull;
                 const u32 len = (u32)desc[u] & DESC_LEN_MASK;
-                nch[u] = (len + G - 1) >> 4;
+                const u32 n_units = (len + G - 1) >> 4;
                 unit[u] = (u32)(desc[u] >> DESC_LEN_BITS) >> 4;
-                wf[u] = ws[u] & 63u;
-                wsp[u] = ws[u] >> 6;
-                defer = defer || (nch[u] != 0 && wsp[u] == 3u);  // a row over more than three windows: the other kernel's business
+                pk[u] = n_units ? (n_units | ((ws[u] & 0xFFu) << 16)) : 0u;
+                defer = defer || n_units > 0xFFFFu || WSP(u) == 3u;  // a row over more than three windows: the other kernel's business
             }
         }
         defer = __any(defer);
@@ -1916,10 +1918,10 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
         if (!defer) {
 #pragma unroll
             for (int u = 0; u < PU; u++) {
-                if (nch[u]) {
-                    atomicAdd(&tlw[wf[u]], nch[u]);
-                    if (wsp[u] >= 1u) atomicAdd(&tlw[wf[u] + 1u], nch[u]);
-                    if (wsp[u] >= 2u) atomicAdd(&tlw[wf[u] + 2u], nch[u]);
+                if (pk[u]) {
+                    atomicAdd(&tlw[WF(u)], NCH(u));
+                    if (WSP(u) >= 1u) atomicAdd(&tlw[WF(u) + 1u], NCH(u));
+                    if (WSP(u) >= 2u) atomicAdd(&tlw[WF(u) + 2u], NCH(u));
                 }
             }
         }
@@ -1966,10 +1968,10 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
         //      operations of a wave execute in program order).  Every turn has a result register of its own, so that the sixteen
         //      adds of a slot are issued back to back (one register for all of them made every add wait for the one before);
         //      the lane then picks its own turn's result ----
-        u32 place[PU];
 #pragma unroll
         for (int u = 0; u < PU; u++) {
-            const bool spans = __any(nch[u] != 0 && wsp[u] != 0u);
+            const u32 nch = NCH(u), wf = WF(u), wsp = WSP(u);
+            const bool spans = __any(wsp != 0u);
             u32 pl = 0;
 #pragma unroll 1
             for (u32 tq = 0; tq < (u32)G; tq += 4) {  // four turns at a time: four adds in flight, one wait (sixteen at a time cost 100 registers)
@@ -1977,15 +1979,15 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     got[j] = 0;
-                    const bool mine = li == tq + (u32)j && nch[u] != 0;
-                    if (mine) got[j] = atomicAdd(&tlw[wf[u]], nch[u]);
+                    const bool mine = li == tq + (u32)j && nch != 0;
+                    if (mine) got[j] = atomicAdd(&tlw[wf], nch);
                     if (spans) {  // (rare, wave-uniform: rows that reach into the next window or two are listed there as well, at the same turn)
-                        if (__any(mine && wsp[u] != 0u)) {
+                        if (__any(mine && wsp != 0u)) {
                             u32 p1 = 0, p2 = 0;
-                            if (mine && wsp[u] >= 1u) p1 = atomicAdd(&tlw[wf[u] + 1u], nch[u]);
-                            if (mine && wsp[u] >= 2u) p2 = atomicAdd(&tlw[wf[u] + 2u], nch[u]);
-                            if (mine && wsp[u] >= 1u) for (u32 c = 0; c < nch[u]; c++) items[p1 + c] = (unit[u] + c) << 7;
-                            if (mine && wsp[u] >= 2u) for (u32 c = 0; c < nch[u]; c++) items[p2 + c] = (unit[u] + c) << 7;
+                            if (mine && wsp >= 1u) p1 = atomicAdd(&tlw[wf + 1u], nch);
+                            if (mine && wsp >= 2u) p2 = atomicAdd(&tlw[wf + 2u], nch);
+                            if (mine && wsp >= 1u) for (u32 c = 0; c < nch; c++) items[p1 + c] = (unit[u] + c) << 7;
+                            if (mine && wsp >= 2u) for (u32 c = 0; c < nch; c++) items[p2 + c] = (unit[u] + c) << 7;
                         }
                     }
                 }
@@ -1993,14 +1995,10 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                 for (int j = 0; j < 4; j++) pl = li == tq + (u32)j ? got[j] : pl;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            place[u] = pl;
-        }
-#pragma unroll
-        for (int u = 0; u < PU; u++) {
-            if (nch[u] > 0) items[place[u]] = unit[u] << 7;  // item = byte offset of the 128-byte unit
-            if (nch[u] > 1) items[place[u] + 1u] = (unit[u] + 1u) << 7;
-            for (u32 c = 2; __any(c < nch[u]); c++)
-                if (c < nch[u]) items[place[u] + c] = (unit[u] + c) << 7;
+            if (nch > 0) items[pl] = unit[u] << 7;  // item = byte offset of the 128-byte unit
+            if (nch > 1) items[pl + 1u] = (unit[u] + 1u) << 7;
+            for (u32 c = 2; __any(c < nch); c++)
+                if (c < nch) items[pl + c] = (unit[u] + c) << 7;
         }
         wave_lds_fence();
         // the counters have done their work: their first words become the touched bitmap; every slot of S starts from this read's Q * T
@@ -2026,23 +2024,15 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
         bool doubt = false;
         Heads4 hd;
         heads_clear(hd);
-        float tie_v = -INFINITY;  // largest score that arrived equal to a kept one of its stream
         // second pass of a tile in doubt: every entry at or above the K-th score the first pass found is a CANDIDATE (the true K best
         // are among them, and they are few); a lane keeps up to three, the group's <= 48 are ranked exactly at the end
         u32 tau_o = 0;
         u64 cand0 = 0, cand1 = 0, cand2 = 0;  // (a tile is in doubt BECAUSE some lane holds three of the best: two would never do)
         bool cand_over = false;
-        for (int phase = 0; phase < 2; phase++) {
-            if (phase == 1) {
-                if (!__any(doubt)) break;
-#ifdef RK_STAMPS
-                st_[15] += 1;
-#endif
-                const int num0 = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
-                u32 t_o = acc_key != 0ull ? ~(u32)(acc_key >> 32) : 0u;  // smallest ordered score among the winners = largest complement
-                t_o = group_max_u32<G>(t_o);
-                tau_o = num0 >= K ? ~t_o : 0u;  // (fewer than K found: everything is a candidate -- the tile then goes to the other kernel)
-            }
+        // the stream, once for the fast pass (PH = 0) and once more for the tiles in doubt (PH = 1): two copies of the code, each with
+        // its own select at the window ends (one copy with the pass as a variable kept both passes' state alive through every loop)
+        auto run_stream = [&](auto ph) {
+            constexpr int PH = decltype(ph)::value;
             // ---- fast pass ----
             u32 wcur = nonempty ? (u32)__builtin_ctzll(nonempty) : 0u;
             u64 left = nonempty & (nonempty - 1);
@@ -2065,7 +2055,7 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                 // otherwise all land in stream 0): a rotation by wcur & 3, in two conditional steps
                 const bool r1 = (wcur & 1u) != 0u, r2 = (wcur & 2u) != 0u;
                 const u32 wlom15 = wlo - 15u;
-                while (__any(m != 0)) {
+                if (__any(m != 0)) do {
                     u32 sbt[4], sbv[4], val[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {  // byte offset of the slot in S (below 64 = none: the lane's scratch word)
@@ -2083,17 +2073,10 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                         val[c] = *ps;
                         *ps = QTbits;
                     }
-                    if (phase == 0) {
+                    if (PH == 0) {
                         const bool h0 = sbv[0] >= 64u, h1 = sbv[1] >= 64u, h2 = sbv[2] >= 64u, h3 = sbv[3] >= 64u;
                         const float f0 = h0 ? __uint_as_float(val[0]) : -INFINITY, f1 = h1 ? __uint_as_float(val[1]) : -INFINITY,
                                     f2 = h2 ? __uint_as_float(val[2]) : -INFINITY, f3 = h3 ? __uint_as_float(val[3]) : -INFINITY;
-                        // equal scores inside one stream: their order is the slots', which the streams here do not keep -> second pass
-                        // (it matters only if that score could be among the K best: decided after the rounds)
-                        // (a lane without a slot feeds -inf: never equal to a kept score that matters, never kept)
-                        tie_v = fmaxf(tie_v, (f0 == hd.s0[0] || f0 == hd.s1[0]) ? f0 : -INFINITY);
-                        tie_v = fmaxf(tie_v, (f1 == hd.s0[1] || f1 == hd.s1[1]) ? f1 : -INFINITY);
-                        tie_v = fmaxf(tie_v, (f2 == hd.s0[2] || f2 == hd.s1[2]) ? f2 : -INFINITY);
-                        tie_v = fmaxf(tie_v, (f3 == hd.s0[3] || f3 == hd.s1[3]) ? f3 : -INFINITY);
                         heads_feed<0>(hd, f0, wlom15 + (sbv[0] >> 2));  // slot id = branch + 1
                         heads_feed<1>(hd, f1, wlom15 + (sbv[1] >> 2));
                         heads_feed<2>(hd, f2, wlom15 + (sbv[2] >> 2));
@@ -2109,7 +2092,7 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                             cand0 = (is && cand0 == 0ull) ? key : cand0;
                         }
                     }
-                }
+                } while (__any(m != 0));
                 wave_lds_fence();
                 if (left) {
                     wcur = (u32)__builtin_ctzll(left);
@@ -2189,11 +2172,24 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                     RK_STAMP(2);
                 }
             }
-            // (what is left in the ring are fillers: loads without a memory request)
-            if (phase == 0) {
+        };
+        // ---- fast pass ----
+        run_stream(std::integral_constant<int, 0>());
+        // (what is left in the ring are fillers: loads without a memory request)
+        {
                 u32 win_o, win_i;
                 bool d0;
                 u32 kth_o;
+                // Equal scores inside one stream: their order is the slots', which a stream fed in any order does not keep.  Whatever
+                // arrived equal to a kept score is still to be seen at the end: equal to the best -> it is the second (s0 == s1); equal
+                // to the second -> it was dropped (dr == s1); and once larger scores have pushed both out they are dropped candidates,
+                // which the rounds judge anyway.  The largest such score matters only if it could be among the K best.
+                float tie_v = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bool t = hd.s1[c] != -INFINITY && (hd.s0[c] == hd.s1[c] || hd.dr[c] == hd.s1[c]);
+                    tie_v = fmaxf(tie_v, t ? hd.s1[c] : -INFINITY);
+                }
                 const int num = heads_rounds_raw<G, true>(hd, K, li, gi, win_o, win_i, d0, &kth_o);
                 acc_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
                 const bool tie = tie_v != -INFINITY && ord_f32(tie_v) >= kth_o;
@@ -2202,7 +2198,19 @@ __global__ void __launch_bounds__(256) place_packed16s_kernel(PlaceArgs a) {
                 st_[13] += __any(d0) ? 1 : 0;   // (diagnostic: tiles in doubt because of a dropped candidate, as against a tie)
 #endif
                 RK_STAMP(5);  // rounds
-            } else {
+        }
+        if (__any(doubt)) {
+#ifdef RK_STAMPS
+            st_[15] += 1;
+#endif
+            {
+                const int num0 = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+                u32 t_o = acc_key != 0ull ? ~(u32)(acc_key >> 32) : 0u;  // smallest ordered score among the winners = largest complement
+                t_o = group_max_u32<G>(t_o);
+                tau_o = num0 >= K ? ~t_o : 0u;  // (fewer than K found: everything is a candidate -- the tile then goes to the other kernel)
+            }
+            run_stream(std::integral_constant<int, 1>());
+            {
                 // the group's candidates ranked exactly (keys are unique); more than two in one lane: the other kernel's business
                 work64[li] = cand0;
                 work64[G + li] = cand1;

@@ -157,7 +157,8 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     sp.surv_n = (uint32_t)surv.size();
 
     WindowPlan wp;
-    const bool want_windows = window_plan(d->n_branches, wp);  // (used only when the image turns out not to be an indexed one)
+    const uint32_t sym_bits = d->alphabet == RK_ALPHABET_DNA ? 2u : 5u;
+    const bool want_windows = window_plan(d->n_branches, sym_bits, wp);  // (used only when the image turns out not to be an indexed one)
     std::vector<unsigned char> winspec;  // [space] winspec_byte(first, last window) of every row (rows are branch runs)
     if (want_windows) {
         try { winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create_synth: host OOM"); }
@@ -207,7 +208,7 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
     const double mean_len = n_keys ? (double)n_entries / (double)n_keys : 0.0;
     uint64_t slot_units = 1;
     for (uint64_t i = 0; i < n_keys; i++) slot_units += (lens32[i] + ROW_UNIT - 1) / ROW_UNIT;
-    const ImageKind kind = image_kind(d->n_branches, d->table_mode, space, true, slot_units, max_len, mean_len);
+    const ImageKind kind = image_kind(d->n_branches, sym_bits, d->table_mode, space, true, slot_units, max_len, mean_len);
     const bool indexed = kind.indexed;
     const uint64_t unit_bytes = indexed ? 64 : ROW_UNIT * 8;
     uint64_t blob_units = 1, max_units = 0;
