@@ -1228,7 +1228,11 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         const uint32_t need = 200 + 5 * wp.n_win + 3 * ring;
         const uint32_t s_str = wp.W + 16;  // a scratch word per lane in front of the window's slots
         uint32_t budget = 0;
-        for (uint32_t waves : {8u, 7u, 6u, 5u}) {
+        // two waves per SIMD (182 registers for DNA, 255 for amino acids).  Tried: three (167 registers, 28 bytes of scratch) and
+        // the nine to eleven waves per CU the LDS then allows -- T8k 137 -> 97, T20k 102 -> 93 Mreads/s: the kernel is bound by
+        // instruction issue, not by latency
+        const uint32_t max_waves = 8u;
+        for (uint32_t waves = max_waves; waves >= 5u; waves--) {
             budget = (160 * 1024 / waves / 512 * 512) / 4 / 4;  // (whole 512-byte granules per wave: see resident_blocks)
             if (budget >= s_str + work + need) break;
         }
@@ -1239,7 +1243,7 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         const size_t lds_wave = (size_t)4 * (b.s_stride + b.main_cap + b.work_cap) * 4;
         uint32_t waves_cu = (uint32_t)(db->lds_per_cu / lds_wave);
         if (waves_cu < 1) return fail(RK_ERR_UNSUPPORTED, "internal: windowed geometry does not fit the LDS");
-        if (waves_cu > 8) waves_cu = 8;
+        if (waves_cu > max_waves) waves_cu = max_waves;
         auto launch = [&](auto kern) -> int {
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
             uint64_t per_cu = 0;

@@ -42,8 +42,11 @@ if prefix:
             w.writerows(stats)
     with open(prefix + "_pmc_summary.txt", "w") as fh:
         fh.write("\n".join(lines) + "\n")
-    for k, d in agg.items():
-        if "rk::place_" in k and "place_ascii" not in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    # the dominant placement kernel (the one that fetched most: place_packed16s_kernel hands a few tiles to a second launch)
+    cands = [k for k, d in agg.items() if "rk::place_" in k and "place_ascii" not in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d]
+    cands.sort(key=lambda k: -sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"]))
+    for k, d in [(k, agg[k]) for k in cands[:1]]:
+        if True:
             fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
             write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
             meta = json.loads(os.environ.get("PROF_META", "{}"))
