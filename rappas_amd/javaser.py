@@ -147,8 +147,19 @@ class Reader:
         n = self._u1() if tc == TC_BLOCKDATA else self._i4()
         return bytes(self._take(n))
 
+    MAX_DEPTH = 3000  # (rk_javaser.hpp's cap; a JVM's own stack gives out long before)
+
     def content(self):
         """one `object` production"""
+        self.depth = getattr(self, "depth", 0) + 1
+        try:
+            if self.depth > self.MAX_DEPTH:
+                raise JavaSerializationError(f"objects nested too deep (more than {self.MAX_DEPTH} levels)", self.p)
+            return self._content()
+        finally:
+            self.depth -= 1
+
+    def _content(self):
         at = self.p
         tc = self._u1()
         if tc == TC_NULL:
