@@ -1097,7 +1097,9 @@ struct Geometry {
     uint32_t waves_per_cu;
 };
 
-static uint32_t probe_unroll(uint32_t G) { return G <= 16 ? 9 : (G == 32 ? 5 : 3); }  // PU*G >= 144 positions per batch
+// PU*G >= 144 positions per probe batch.  Amino acids through the 16-lane kernels: a packed record of <= 16 words holds <= 102
+// residues, so seven rounds of sixteen are a whole read (nine made C4 look up 48 k-mers per read that do not exist)
+static uint32_t probe_unroll(uint32_t G, uint32_t bits) { return G <= 16 ? (bits == 5 && G == 16 ? 7 : 9) : (G == 32 ? 5 : 3); }
 
 static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) {
     const uint32_t nb = db->info.n_branches;
@@ -1118,7 +1120,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
         else if (keep_at_most <= 32 && bytes_for(32, 32 + 3 * RK_RING + 40) <= db->lds_per_cu / 4) G = 32;
     }
     if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
-    const uint32_t NG = 64 / G, pu = probe_unroll(G);
+    const uint32_t NG = 64 / G, pu = probe_unroll(G, db->info.bits_per_symbol);
     const uint32_t min_cap = G + 3 * RK_RING + 40;  // one sub-batch of rows + sentinel, ring slack, 16 winner slots + margin
     // list capacity: whatever is left of the per-wave LDS target, clamped to [min_cap, 256]
     size_t per_group_target = target / NG;
@@ -1154,7 +1156,7 @@ static bool use_pipelined16(const rk_db *db, const Geometry &g, const PlaceArgs 
 
 template <int G, int BITS, int TM, bool WIDE>
 static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
-    constexpr int PU = G <= 16 ? 9 : (G == 32 ? 5 : 3);
+    constexpr int PU = G <= 16 ? (BITS == 5 && G == 16 ? 7 : 9) : (G == 32 ? 5 : 3);  // (= probe_unroll)
     constexpr int U = RK_RING;
     auto kern = place_packed_kernel<G, BITS, TM, WIDE, U, PU>;
     if constexpr (G == 16 && !WIDE && TM != TM_HASH) {
@@ -1256,7 +1258,7 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         int rc;
         const bool wide = wp.W > 512;  // two bitmap words a lane
         if (db->info.bits_per_symbol == 2) rc = wide ? launch(place_packed16s_kernel<2, 8, 9, true>) : launch(place_packed16s_kernel<2, 8, 9, false>);
-        else rc = wide ? launch(place_packed16s_kernel<5, 8, 9, true>) : launch(place_packed16s_kernel<5, 8, 9, false>);
+        else rc = wide ? launch(place_packed16s_kernel<5, 8, 7, true>) : launch(place_packed16s_kernel<5, 8, 7, false>);  // (<= 102 residues in 16 words)
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
     }
@@ -1466,8 +1468,8 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     }
     if (use_windowed(db, 7, 16)) {
         if (wstream_tree(db->info.n_branches, db->info.bits_per_symbol) && !rk_knob("RK_NO_WSTREAM"))
-            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=9,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
-                     db->info.bits_per_symbol, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
+            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
+                     db->info.bits_per_symbol, db->info.bits_per_symbol == 5 ? 7 : 9, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
         else
         snprintf(buf, sizeof(buf), "place_packed16w_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches lds/wave=%zuB main=%u work=%u",
                  db->info.bits_per_symbol, RK_WRING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),
