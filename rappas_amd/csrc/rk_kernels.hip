@@ -1804,7 +1804,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int U, int PU, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16s_kernel(PlaceArgs a) {  // (amino acids: 264 registers left to itself, one wave per SIMD)
-    constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2;
+    constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2, TURNS = 8;
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
@@ -1912,8 +1912,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             }
         }
         defer = __any(defer);
+        RK_STAMP(4);  // (diagnostic split of the emit: probe)
         // ---- units per window and read: tlw[w], w < 64 ----
         *(uint4 *)(tlw + 4 * li) = make_uint4(0u, 0u, 0u, 0u);
+        u32 *idle = tlw + 64 + li;  // a word of the lane's own, always 0: where the lanes whose turn it is not add nothing
+        *idle = 0u;
         wave_lds_fence();
         if (!defer) {
 #pragma unroll
@@ -1964,6 +1967,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
         }
         for (int i = (int)li; i < total + 3 * U; i += G) items[i] = ITEM_FILLER;
         wave_lds_fence();
+        RK_STAMP(8);  // (counts, segments, fillers)
         // ---- places: one returning add per row and window, in k-mer order (u-major, then the lanes of the group in turn: LDS
         //      operations of a wave execute in program order).  Every turn has a result register of its own, so that the sixteen
         //      adds of a slot are issued back to back (one register for all of them made every add wait for the one before);
@@ -1971,36 +1975,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #pragma unroll
         for (int u = 0; u < PU; u++) {
             const u32 nch = NCH(u), wf = WF(u), wsp = WSP(u);
-            const bool spans = __any(wsp != 0u);
-            u32 pl = 0;
+            const u64 spm = __ballot(wsp != 0u);  // rows of this round that reach into the next window or two: listed there as well
+            const bool spans = spm != 0ull;
+            u32 pl0 = 0, pl1 = 0, pl2 = 0;
 #pragma unroll 1
-            for (u32 tq = 0; tq < (u32)G; tq += 4) {  // four turns at a time: four adds in flight, one wait (sixteen at a time cost 100 registers)
-                u32 got[4];
+            for (u32 tq = 0; tq < (u32)G; tq += TURNS) {  // TURNS turns at a time: their adds are in flight together, one wait
+                u32 g0[TURNS], g1[TURNS], g2[TURNS];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    got[j] = 0;
-                    const bool mine = li == tq + (u32)j && nch != 0;
-                    if (mine) got[j] = atomicAdd(&tlw[wf], nch);
-                    if (spans) {  // (rare, wave-uniform: rows that reach into the next window or two are listed there as well, at the same turn)
-                        if (__any(mine && wsp != 0u)) {
-                            u32 p1 = 0, p2 = 0;
-                            if (mine && wsp >= 1u) p1 = atomicAdd(&tlw[wf + 1u], nch);
-                            if (mine && wsp >= 2u) p2 = atomicAdd(&tlw[wf + 2u], nch);
-                            if (mine && wsp >= 1u) for (u32 c = 0; c < nch; c++) items[p1 + c] = (unit[u] + c) << 7;
-                            if (mine && wsp >= 2u) for (u32 c = 0; c < nch; c++) items[p2 + c] = (unit[u] + c) << 7;
-                        }
+                for (int j = 0; j < TURNS; j++) {
+                    // every lane adds -- the others 0 to a word of their own: no exec masks to set up and take down -- and the turn's
+                    // lane of each read gets the row's place back
+                    const bool me = li == tq + (u32)j;
+                    g1[j] = 0; g2[j] = 0;
+                    g0[j] = atomicAdd(me ? &tlw[wf] : idle, me ? nch : 0u);
+                    // (the same turn: a window's counter sees its rows in k-mer order whichever way they came to it.  Behind a branch of
+                    //  the whole wave: an LDS atomic costs its ~40 cycles with every lane masked off, too)
+                    if (spm & __ballot(me)) {
+                        if (me && wsp >= 1u) g1[j] = atomicAdd(&tlw[wf + 1u], nch);
+                        if (me && wsp >= 2u) g2[j] = atomicAdd(&tlw[wf + 2u], nch);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) pl = li == tq + (u32)j ? got[j] : pl;
+                for (int j = 0; j < TURNS; j++) {
+                    const bool me = li == tq + (u32)j;
+                    pl0 = me ? g0[j] : pl0;
+                    if (spans) {
+                        pl1 = me ? g1[j] : pl1;
+                        pl2 = me ? g2[j] : pl2;
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (nch > 0) items[pl] = unit[u] << 7;  // item = byte offset of the 128-byte unit
-            if (nch > 1) items[pl + 1u] = (unit[u] + 1u) << 7;
+            // items = byte offsets of the row's 128-byte units, at the row's place in every window it is listed in
+            if (nch > 0) items[pl0] = unit[u] << 7;
+            if (nch > 1) items[pl0 + 1u] = (unit[u] + 1u) << 7;
             for (u32 c = 2; __any(c < nch); c++)
-                if (c < nch) items[pl + c] = (unit[u] + c) << 7;
+                if (c < nch) items[pl0 + c] = (unit[u] + c) << 7;
+            if (spans) {
+                for (u32 c = 0; __any(c < nch && wsp >= 1u); c++) {
+                    if (c < nch && wsp >= 1u) items[pl1 + c] = (unit[u] + c) << 7;
+                    if (c < nch && wsp >= 2u) items[pl2 + c] = (unit[u] + c) << 7;
+                }
+            }
         }
         wave_lds_fence();
+        RK_STAMP(9);  // (places + items)
         // the counters have done their work: their first words become the touched bitmap; every slot of S starts from this read's Q * T
         const u32 QTbits = __float_as_uint(QT);
         bm[li] = 0u;

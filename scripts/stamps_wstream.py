@@ -3,7 +3,7 @@ C2-like database spread over a tree of --branches=N branches (s_memtime stamps, 
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "rappas_amd", "variants", "librk_stamps.so")
+so = os.environ.get("RK_STAMPS_LIB") or os.path.join(ROOT, "rappas_amd", "variants", "librk_stamps.so")
 if not os.path.exists(so) or "--rebuild" in sys.argv:
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DRK_DEV_KNOBS", "-DRK_STAMPS",
@@ -37,7 +37,7 @@ for branches in [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--b
         t = s[:, 11].sum()
         print(f"  per placed tile: list {s[:, 12].sum() / t:.1f} steps; tiles in doubt because a stream dropped a candidate {int(s[:, 13].sum())} (the rest of the redone ones: ties)")
         tot = s[:, :10].sum()
-        for i, nm in enumerate(["tile setup", "probe + count + sort", "touched-slot select at window ends", "stream steps", "-", "rounds", "exact redo (rest in 8/9)", "weigh + store", "exact redo: select scan", "exact redo: select rest"]):
+        for i, nm in enumerate(["tile setup", "emit: S and bitmap reset (the rest of probe + count + sort)", "touched-slot select at window ends", "stream steps", "emit: probe", "rounds", "exact redo (rest in 8/9)", "weigh + store", "emit: counts, segments, fillers", "emit: places + items"]):
             if s[:, i].sum(): print(f"    {nm:40s} {100 * s[:, i].sum() / tot:5.1f} %  {s[:, i].sum() / t:9.0f} cycles per placed tile")
     if len(w): print(f"  place_packed16w_kernel behind it: {len(w)} waves, {w[:, :8].sum() / max(1.0, s[:, :8].sum()) * 100:.1f} % of the first kernel's wave cycles")
     db.close()

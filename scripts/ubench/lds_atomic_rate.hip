@@ -27,6 +27,8 @@ __global__ void __launch_bounds__(64) k(u32 *out, int iters) {
                 if (OP == 3) { const u32 o = *(volatile u32 *)q; *(volatile u32 *)q = o + 1; }
                 if (OP == 4) acc += __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (OP == 5) __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (OP == 6) acc += __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // the SAME word, instruction after instruction
+                if (OP == 7) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
     }
@@ -66,6 +68,9 @@ int main() {
     run<2, 64, true>("ds_or_b32 (no return)");
     run<5, 64, false>("ds_add_u32 (no return)");
     run<4, 64, false>("ds_add_rtn_u32");
+    run<6, 64, false>("ds_add_rtn_u32, same word again");
+    run<6, 4, false>("ds_add_rtn_u32, same word again");
+    run<7, 64, false>("ds_add_u32, same word again");
     run<3, 64, false>("ds_read_b32 + ds_write_b32");
     run<3, 16, false>("ds_read_b32 + ds_write_b32");
     return 0;
