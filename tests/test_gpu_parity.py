@@ -782,7 +782,7 @@ def test_windowed_kernel_protein_on_large_trees(n_branches):
     (20, 3, 3100, 6000, 60000, 90), (20, 3, 20001, 7000, 80000, 100)])
 def test_sorted_stream_kernel_on_every_windowed_tree(alphabet, k, n_branches, n_keys, n_entries, length, monkeypatch, dev_lib):
     """place_packed16s_kernel (the round-3 windowed kernel: row units sorted by window, one accumulate stream, touched-slot lists)
-    forced onto every windowed tree (it is the default only beyond 8 192 branches), for keep_at_most 1 ... 16, both ambiguity modes,
+    forced onto every windowed tree (it is the default beyond 4 500 branches, and for every windowed protein tree), for keep_at_most 1 ... 16, both ambiguity modes,
     reads with ambiguity codes / unsupported characters / ragged lengths, rows scattered over all windows (tiles it hands over to
     place_packed16w_kernel), and scores below the threshold (the general first-touch path)"""
     monkeypatch.setenv("RK_WSTREAM_ALWAYS", "1")
@@ -804,6 +804,25 @@ def test_sorted_stream_kernel_on_every_windowed_tree(alphabet, k, n_branches, n_
         scat = _scatter_rows(synth.make_db(4, 7, n_branches, 12000, 150000, seed=length), seed=n_branches)
         s2, o2 = synth.make_reads(4, 600, length, seed=3)
         run_case(scat, O.OracleDB.from_synth(scat), s2, o2, "direct", 0, "mean")
+
+
+@pytest.mark.parametrize("n_branches", [399, 1500, 9001])
+def test_protein_records_filled_to_the_last_word(n_branches):
+    """amino-acid reads of 95 ... 102 residues: what a 16-word record can hold, and all that the 16-lane kernels' seven probe rounds
+    (7 x 16 = 112 k-mers) have to cover -- dense kernel, and both windowed kernels behind the switch"""
+    sdb = synth.make_db(20, 5, n_branches, 30000, 300000, seed=n_branches)
+    odb = O.OracleDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "PU=7" in db.kernel_name(), db.kernel_name()
+    db.close()
+    rng = np.random.default_rng(n_branches)
+    lens = rng.integers(95, 103, 1200)
+    lens[:8] = [102, 102, 101, 100, 99, 98, 97, 96]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)[rng.integers(0, 20, int(off[-1]))].copy()
+    for K in (7, 16):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K)
+        assert st["placed"] > 300
 
 
 def test_dense_rows_on_a_mid_size_tree_take_the_dense_kernels():
