@@ -362,6 +362,8 @@ static inline bool windows_pay(uint32_t nb, uint64_t blob_units, uint64_t space)
 }
 struct WindowPlan {
     uint32_t W = 0, n_win = 0, s_stride = 0, main_cap = 0, work_cap = 0;
+    bool stream = false;          // place_packed16s_kernel first (decided when the image is built: its windows are narrower)
+    double units_per_code = 0.0;  // row units / k-mer codes of the alphabet: what a read's k-mer brings on average
 };
 
 // The dense 16-lane geometry keeps eight waves per CU up to 1 116 branches (choose_geometry); beyond that -- and up to the
@@ -370,20 +372,34 @@ struct WindowPlan {
 #ifndef RK_WSTREAM_MIN_BRANCHES
 #define RK_WSTREAM_MIN_BRANCHES 4500u
 #endif
-static bool wstream_tree(uint32_t nb, uint32_t bits) {  // trees whose tiles go to place_packed16s_kernel first
+// Row units a 150-symbol read brings (its ~150 k-mers x the row units per k-mer CODE of the image) beyond which the sorted list of
+// place_packed16s_kernel stops fitting and place_packed16w_kernel alone is ahead: scripts/long_rows_big_tree.py, 9 001 branches,
+// a quarter of the 9-mers present, rows of 70 / 150 / 300 entries (~170 / 350 / 680 units a read): 73 / 35 / 15 Mreads/s with the
+// second kernel first, 77 / 46 / 21 without (profiles/r03_long_rows_big_tree.txt)
+#ifndef RK_WSTREAM_MAX_UNITS
+#define RK_WSTREAM_MAX_UNITS 220.0
+#endif
+static bool wstream_tree(uint32_t nb, uint32_t bits, double units_per_code, double units_per_row) {  // images whose tiles go to place_packed16s_kernel first
     if (rk_knob("RK_WSTREAM_ALWAYS")) return true;  // developer / test knob: the sorted-stream kernel on every windowed tree
+    if (150.0 * units_per_code > RK_WSTREAM_MAX_UNITS) return false;
+    // rows of several units (70 entries: 5) put few, long runs of slots into a window -- three or four rounds at its end -- and few
+    // units per window and read, so that most of the list is padding: 9 001 / 15 999 / 25 001 branches 73 / 44 / 28 Mreads/s against
+    // 77 / 53 / 39 (same profile); short rows only
+    if (units_per_row > 2.5) return false;
     // amino acids: every windowed tree (the first kernel runs with register spills to keep two waves per SIMD: 274 / 248 / 194
     // Mreads/s at 1 400 / 1 999 / 3 999 branches against 280 / 272 / 241, C4-like rows; profiles/r03_wstream_crossover.txt)
     return bits == 5 || nb > RK_WSTREAM_MIN_BRANCHES;
 }
-static bool window_plan(uint32_t nb, uint32_t bits, WindowPlan &wp) {
+static bool window_plan(uint32_t nb, uint32_t bits, double units_per_code, double units_per_row, WindowPlan &wp) {
     if (nb <= RK_WINDOW_MIN_BRANCHES || nb > RK_WG_ALWAYS_BRANCHES) return false;
     // up to ~4 500 branches place_packed16w_kernel is ahead (windows of <= 1 024 branches, as few as possible: it pays per window);
     // beyond, place_packed16s_kernel (round 3: a window's cost follows what the read touches in it, so more and smaller windows --
     // about 500 branches, one bitmap word a lane -- cost little and leave the LDS to the list).  At most 64 windows: up to 1 024
     // branches each on the largest trees.  scripts/wstream_crossover.py, Mreads/s at 3 999 / 4 999 / 5 999 / 7 999 branches:
     // 164 / 147 / 132 / 113 with the first kernel, 159 / 150 / 144 / 135 with the second (profiles/r03_wstream_crossover.txt)
-    uint32_t n_win = wstream_tree(nb, bits) ? (nb + 511) / 512 : (nb + 895) / 896;
+    wp.stream = wstream_tree(nb, bits, units_per_code, units_per_row);
+    wp.units_per_code = units_per_code;
+    uint32_t n_win = wp.stream ? (nb + 511) / 512 : (nb + 895) / 896;
     if (n_win > RK_MAX_WINDOWS) n_win = RK_MAX_WINDOWS;
     wp.n_win = n_win;
     wp.W = ((nb + n_win - 1) / n_win + 3) & ~3u;
@@ -412,10 +428,15 @@ struct ImageKind { bool indexed, windowable; };
 static ImageKind image_kind(uint32_t nb, uint32_t bits, uint32_t table_mode, uint64_t space, bool space_ok, uint64_t slot_units, uint32_t max_len, double mean_len) {
     WindowPlan wp;
     const bool direct = table_mode == RK_TABLE_DIRECT || (table_mode == RK_TABLE_AUTO && space_ok && space <= (1ull << 28));
-    const bool windowable = window_plan(nb, bits, wp) && direct && (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB &&
+    const bool windowable = window_plan(nb, bits, space ? (double)slot_units / (double)space : 0.0, mean_len / ROW_UNIT + 0.5, wp) && direct && (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB &&
                             windows_pay(nb, slot_units, space);
     const bool long_rows = mean_len >= RK_WG_MIN_MEAN_ROW;
-    const bool indexed = nb > RK_WG_MIN_BRANCHES && (long_rows || (!windowable && nb > 16000u));
+    // Between its two regimes (slices of a row shorter than a turn of the ring) the workgroup-per-read kernel is behind the dense
+    // 64-lane one while that still has three or four reads per CU: scripts/long_rows_big_tree.py, rows of 400 / 1 000 entries, Mreads/s,
+    // dense against workgroup: 9 001 branches 31.0 / 14.3 against 16.2 / 12.3; 11 001: 22.2 / 11.0 against 16.0 / 12.1; 13 001: 21.3 /
+    // 10.7 against 15.9 / 12.1; 15 999: 13.5 / 7.2 against 15.8 / 11.9 (profiles/r03_long_rows_big_tree.txt)
+    const bool dense64_ahead = (nb <= 9900u && mean_len < 1200.0) || (nb <= 13300u && mean_len < 750.0);
+    const bool indexed = nb > RK_WG_MIN_BRANCHES && ((long_rows && !dense64_ahead) || (!windowable && nb > 16000u));
     return {indexed, windowable && !indexed};
 }
 
@@ -711,7 +732,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     img.indexed = indexed;
     std::vector<uint64_t> desc(n_keys);  // by key number
     WindowPlan wp;
-    const bool want_windows = kind.windowable && window_plan(d->n_branches, bits, wp);
+    const bool want_windows = kind.windowable && window_plan(d->n_branches, bits, space ? (double)slot_units / (double)space : 0.0, mean_len / ROW_UNIT + 0.5, wp);
     std::vector<unsigned char> ws_by_key;  // winspec_byte(first window, last window) of every row
     if (want_windows) {
         try { ws_by_key.assign(n_keys, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
@@ -1214,7 +1235,10 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     const uint64_t n_tiles = (a.n_reads + 3) / 4;
     if (!n_tiles) return RK_OK;
     static const bool no_stream = rk_knob("RK_NO_WSTREAM") != nullptr;  // developer knob: place_packed16w_kernel alone (A/B)
-    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wstream_tree(db->info.n_branches, db->info.bits_per_symbol);
+    // (the reads of this batch may be longer than the 150 symbols the image was judged for: their k-mers x the image's row units per code)
+    const uint32_t max_syms = a.lens ? a.words_per_read * 32 / db->info.bits_per_symbol : a.fixed_len;
+    const double est_units = (max_syms > db->info.k ? max_syms - db->info.k + 1 : 0) * wp.units_per_code;
+    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wp.stream && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
     if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
@@ -1467,7 +1491,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
-        if (wstream_tree(db->info.n_branches, db->info.bits_per_symbol) && !rk_knob("RK_NO_WSTREAM"))
+        if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
             snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
                      db->info.bits_per_symbol, db->info.bits_per_symbol == 5 ? 7 : 9, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
         else

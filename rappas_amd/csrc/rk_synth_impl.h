@@ -158,7 +158,9 @@ extern "C" int rk_db_create_synth(const rk_synth_desc *d, rk_db **out) {
 
     WindowPlan wp;
     const uint32_t sym_bits = d->alphabet == RK_ALPHABET_DNA ? 2u : 5u;
-    const bool want_windows = window_plan(d->n_branches, sym_bits, wp);  // (used only when the image turns out not to be an indexed one)
+    // (used only when the image turns out not to be an indexed one; the rows are not drawn yet: their density from the spec)
+    const double upc_spec = ((double)sp.key_thresh / 4294967296.0) * (d->mean_row_len / (double)ROW_UNIT + 0.5);
+    const bool want_windows = window_plan(d->n_branches, sym_bits, upc_spec, d->mean_row_len / (double)ROW_UNIT + 0.5, wp);
     std::vector<unsigned char> winspec;  // [space] winspec_byte(first, last window) of every row (rows are branch runs)
     if (want_windows) {
         try { winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create_synth: host OOM"); }

@@ -24,6 +24,10 @@ CONFIGS = {
     "T8k": (4, 10, 4_000, 786_432, 10_000_000, 150, 4_000_000),
     "T20k": (4, 10, 10_000, 786_432, 10_000_000, 150, 2_000_000),
     "T64k": (4, 10, 32_768, 786_432, 10_000_000, 150, 2_000_000),
+    # not BASELINE configs either: long rows on trees between the dense kernels' and the workgroup-per-read kernel's regimes (a quarter
+    # of the 9-mers present; rows of 400 entries on 9 001 branches, of 1 000 on 15 999: scripts/long_rows_big_tree.py as bench lines)
+    "L9k": (4, 9, 4_501, 65_536, 26_214_400, 150, 300_000),
+    "L16k": (4, 9, 8_000, 65_536, 65_536_000, 150, 300_000),
     "C5mini": (4, 12, 10_000, 1_048_576, 50_000_000, 250, 100_000),  # C5's tree/k at a DB size one test can hold
     # C5-shaped per-read work (19 999 branches, rows of ~2 600 entries, 250 bp => H ~ 4.7e5 entries/read) with a smaller
     # key space (k=8) so that the DB is ~1 GB instead of 200 GB: beyond the Infinity Cache, i.e. HBM-bound like C5

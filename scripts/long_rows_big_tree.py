@@ -6,7 +6,7 @@ import numpy as np, torch
 import rappas_amd as ra
 from rappas_amd import synth
 n = 300_000
-for nb in (9001, 15999, 25001):
+for nb in [int(x) for x in os.environ.get("RK_SIZES", "9001,15999,25001").split(",")]:
     for mean in [int(x) for x in sys.argv[1:]] or [70, 150, 400, 1000]:
         keys = 65536
         sdb = synth.make_db(4, 9, nb, keys, keys * mean, seed=42)  # a quarter of the k-mers present

@@ -101,6 +101,24 @@ def test_large_tree_long_rows_workgroup_kernel(K):
     assert st["placed"] >= 55
 
 
+@pytest.mark.parametrize("n_branches,mean_row,kernel", [(9001, 400, "place_packed_kernel<G=64"), (9001, 1000, "place_packed_kernel<G=64"),
+                                                         (13001, 400, "place_packed"), (13001, 1000, "place_wg_kernel"),
+                                                         (15999, 400, "place_wg_kernel"), (15999, 1000, "place_wg_kernel")])
+def test_long_rows_between_the_dense_and_the_workgroup_regimes(n_branches, mean_row, kernel):
+    """rows of 400 / 1 000 entries on 9 001 ... 15 999 branches (bench.py --config L9k / L16k): the dense 64-lane kernel while a CU still
+    holds three or four score vectors and the rows are short enough (or, where the image can carry window spans, the windowed kernel),
+    the workgroup-per-read kernel beyond (rk_engine.hip: image_kind)"""
+    sdb = _big_tree_db(n_branches, mean_row, seed=n_branches + mean_row)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert kernel in db.kernel_name(), db.kernel_name()
+    db.close()
+    seq, off = synth.make_reads(4, 400, 150, seed=mean_row, amb_rate=0.001, var_len=60)
+    odb = O.OracleDB.from_synth(sdb)
+    for K, amb in ((7, "mean"), (16, "skip")):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, amb, keepAtMost=K)
+        assert st["placed"] > 300
+
+
 def test_large_tree_one_workgroup_per_cu():
     """30 000 branches: only one score vector fits a CU, the workgroup has 16 waves."""
     sdb = synth.make_db(4, 7, 30000, 8000, 2_000_000, seed=12)
