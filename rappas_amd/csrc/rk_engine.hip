@@ -428,15 +428,18 @@ struct ImageKind { bool indexed, windowable; };
 static ImageKind image_kind(uint32_t nb, uint32_t bits, uint32_t table_mode, uint64_t space, bool space_ok, uint64_t slot_units, uint32_t max_len, double mean_len) {
     WindowPlan wp;
     const bool direct = table_mode == RK_TABLE_DIRECT || (table_mode == RK_TABLE_AUTO && space_ok && space <= (1ull << 28));
-    const bool windowable = window_plan(nb, bits, space ? (double)slot_units / (double)space : 0.0, mean_len / ROW_UNIT + 0.5, wp) && direct && (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB &&
-                            windows_pay(nb, slot_units, space);
+    // Just beyond 8 192 branches the dense 64-lane kernel (one wave per read, the whole score vector in the LDS) still holds three or
+    // four reads per CU, and with rows of a few hundred entries it is ahead of both its neighbours (scripts/long_rows_big_tree.py,
+    // scripts/long_rows_lanes64.py, profiles/r03_long_rows_big_tree.txt; Mreads/s, dense against the other):
+    //   the windowed kernel, rows of 150 / 300: 9 001 branches 46.7 / 36.3 against 45.6 / 20.6; 13 001: 30.4 / 24.5 against 39.3 / 19.1;
+    //   the workgroup-per-read kernel between its two regimes (slices of a row shorter than a turn of the ring), rows of 400 / 1 000:
+    //   9 001 branches 31.0 / 14.3 against 16.2 / 12.3; 11 001: 22.2 / 11.0 against 16.0 / 12.1; 13 001: 21.3 / 10.7 against 15.9 / 12.1;
+    //   15 999: 13.5 / 7.2 against 15.8 / 11.9
+    const bool dense64_ahead = nb > RK_WG_MIN_BRANCHES && ((nb <= 9900u && mean_len >= 200.0 && mean_len < 1200.0) || (nb <= 13300u && mean_len >= 250.0 && mean_len < 750.0));
+    const bool windowable = (!dense64_ahead || rk_knob("RK_WINDOW_ALWAYS")) && window_plan(nb, bits, space ? (double)slot_units / (double)space : 0.0, mean_len / ROW_UNIT + 0.5, wp) && direct &&
+                            (max_len + ROW_UNIT - 1) / ROW_UNIT <= 255 && slot_units * 128 < RK_WINDOW_MAX_BLOB && windows_pay(nb, slot_units, space);
     const bool long_rows = mean_len >= RK_WG_MIN_MEAN_ROW;
-    // Between its two regimes (slices of a row shorter than a turn of the ring) the workgroup-per-read kernel is behind the dense
-    // 64-lane one while that still has three or four reads per CU: scripts/long_rows_big_tree.py, rows of 400 / 1 000 entries, Mreads/s,
-    // dense against workgroup: 9 001 branches 31.0 / 14.3 against 16.2 / 12.3; 11 001: 22.2 / 11.0 against 16.0 / 12.1; 13 001: 21.3 /
-    // 10.7 against 15.9 / 12.1; 15 999: 13.5 / 7.2 against 15.8 / 11.9 (profiles/r03_long_rows_big_tree.txt)
-    const bool dense64_ahead = (nb <= 9900u && mean_len < 1200.0) || (nb <= 13300u && mean_len < 750.0);
-    const bool indexed = nb > RK_WG_MIN_BRANCHES && ((long_rows && !dense64_ahead) || (!windowable && nb > 16000u));
+    const bool indexed = nb > RK_WG_MIN_BRANCHES && ((long_rows && !dense64_ahead) || (!windowable && !dense64_ahead && nb > 16000u));
     return {indexed, windowable && !indexed};
 }
 
