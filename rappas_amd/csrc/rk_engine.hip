@@ -50,6 +50,9 @@ using namespace rk;
 #endif
 #ifndef RK_WRING
 #define RK_WRING RK_RING  // the same for the windowed kernel
+#ifndef RK_RING64
+#define RK_RING64 8  // ... and for the 64-lane geometry (one wave per read: large trees with long rows, one or two waves per SIMD)
+#endif
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1145,7 +1148,7 @@ static int choose_geometry(const rk_db *db, uint32_t keep_at_most, Geometry &g) 
     }
     if (G < keep_at_most) return fail(RK_ERR_INVALID, "keep_at_most=%u needs lanes_per_read >= %u", keep_at_most, keep_at_most);
     const uint32_t NG = 64 / G, pu = probe_unroll(G, db->info.bits_per_symbol);
-    const uint32_t min_cap = G + 3 * RK_RING + 40;  // one sub-batch of rows + sentinel, ring slack, 16 winner slots + margin
+    const uint32_t min_cap = G + 3 * (G == 64 ? RK_RING64 : RK_RING) + 40;  // one sub-batch of rows + sentinel, ring slack, 16 winner slots + margin
     // list capacity: whatever is left of the per-wave LDS target, clamped to [min_cap, 256]
     size_t per_group_target = target / NG;
     uint32_t cap = min_cap;
@@ -1181,7 +1184,7 @@ static bool use_pipelined16(const rk_db *db, const Geometry &g, const PlaceArgs 
 template <int G, int BITS, int TM, bool WIDE>
 static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &args, hipStream_t stream) {
     constexpr int PU = G <= 16 ? (BITS == 5 && G == 16 ? 7 : 9) : (G == 32 ? 5 : 3);  // (= probe_unroll)
-    constexpr int U = RK_RING;
+    constexpr int U = G == 64 ? RK_RING64 : RK_RING;
     auto kern = place_packed_kernel<G, BITS, TM, WIDE, U, PU>;
     if constexpr (G == 16 && !WIDE && TM != TM_HASH) {
         if (use_pipelined16(db, g, args)) kern = place_packed16_kernel<BITS, TM, U, PU>;
@@ -1511,7 +1514,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     // records take place_packed_kernel with the same geometry)
     snprintf(buf, sizeof(buf), "%s<G=%u,BITS=%u,%s,%s,U=%d,PU=%u> lds/wave=%zuB cap=%u waves/CU<=%u (LDS; registers may allow fewer)",
              use_pipelined16(db, g, probe) ? "place_packed16_kernel" : "place_packed_kernel", g.G, db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_DIRECT ? (db->compact_nib ? "DIRECT4" : "DIRECT") : (db->info.table_mode == RK_TABLE_DIRECT8 ? "DIRECT8" : "HASH"),
-             db->info.rows_bytes < ROWS_FIT32_LIMIT ? "ITEM32" : "ITEM64", RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
+             db->info.rows_bytes < ROWS_FIT32_LIMIT ? "ITEM32" : "ITEM64", g.G == 64 ? RK_RING64 : RK_RING, g.pu, g.lds_per_wave, g.list_cap, g.waves_per_cu);
     m->kernel_name = buf;
     return m->kernel_name.c_str();
 }
