@@ -1244,7 +1244,10 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     // (the reads of this batch may be longer than the 150 symbols the image was judged for: their k-mers x the image's row units per code)
     const uint32_t max_syms = a.lens ? a.words_per_read * 32 / db->info.bits_per_symbol : a.fixed_len;
     const double est_units = (max_syms > db->info.k ? max_syms - db->info.k + 1 : 0) * wp.units_per_code;
-    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wp.stream && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
+    // (reads of one known length whose k-mers do not fit its single probe batch would all be handed over: not launched for those)
+    const uint32_t probe_cap = (db->info.bits_per_symbol == 5 ? 7u : 9u) * 16u;
+    const bool one_batch = a.lens != nullptr || a.fixed_len < db->info.k || a.fixed_len - db->info.k + 1 <= probe_cap;
+    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
     if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
