@@ -843,6 +843,34 @@ def test_protein_records_filled_to_the_last_word(n_branches):
         assert st["placed"] > 300
 
 
+@pytest.mark.parametrize("seed", range(6 + _EXTRA_SEEDS))
+def test_sorted_stream_kernel_with_scores_from_a_handful_of_values(seed):
+    """equal sums everywhere: every score of the database is one of eight values (dyadic fractions of the threshold, so that sums of
+    them collide exactly), on windowed trees of 4 501 ... 65 535 branches, keep_at_most 1 ... 16.  The stream heads of
+    place_packed16s_kernel are fed in any slot order; a tie that could be among the K best has to send the tile through the exact
+    second pass (or to place_packed16w_kernel) -- the result must be the oracle's branch for branch wherever the oracle's own order is
+    defined (tests/util.py compares exact ties as sets)."""
+    import dataclasses
+    rng = np.random.default_rng(1000 + seed)
+    nb = int(rng.choice([4501, 7000, 9001, 15999, 20001, 33001, 65535]))
+    sdb = synth.make_db(4, 8, nb, 40000, 520000, seed=seed)
+    q = (rng.integers(1, 9, sdb.scores.shape[0]).astype(np.float32) / np.float32(8.0)) * np.float32(sdb.thr_log10)
+    sdb = dataclasses.replace(sdb, scores=q.astype(np.float32))
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_packed16s_kernel" in db.kernel_name(), db.kernel_name()
+    db.close()
+    seq, off = synth.make_reads(4, 2500, 150, seed=seed, var_len=70)
+    K = int(rng.choice([1, 3, 7, 8, 12, 16]))
+    kf = float(rng.choice([0.0, 0.01, 0.5]))
+    got, _, st = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=kf)
+    assert st["placed"] > 2000 and st["ties"] > 50, st
+    # ... and the dense 64-lane kernel's, row for row: among equal scores the engine's order is the branch's, whichever kernel ran
+    if nb <= 33001:  # (beyond, a whole score vector no longer fits a CU's LDS)
+        dense, _, _ = run_case(sdb, O.OracleDB.from_synth(sdb), seq, off, "direct", 64, "mean", keepAtMost=K, keepFactor=kf)
+        assert np.array_equal(got.n_rows, dense.n_rows) and np.array_equal(got.branch, dense.branch)
+        assert np.array_equal(got.score.view(np.uint32), dense.score.view(np.uint32)) and np.array_equal(got.lwr, dense.lwr)
+
+
 def test_dense_rows_on_a_mid_size_tree_take_the_dense_kernels():
     """beyond ~2.2 row units per k-mer code a read's units no longer fit the windowed kernel's lists (scripts/row_length_sweep.py)"""
     sdb = synth.make_db(4, 6, 5001, 4096, 4096 * 60, seed=2)  # every k-mer present, rows of ~60 entries: ~4 units per code
