@@ -1187,7 +1187,13 @@ static int launch_variant(const rk_db *db, const Geometry &g, const PlaceArgs &a
     constexpr int U = G == 64 ? RK_RING64 : RK_RING;
     auto kern = place_packed_kernel<G, BITS, TM, WIDE, U, PU>;
     if constexpr (G == 16 && !WIDE && TM != TM_HASH) {
-        if (use_pipelined16(db, g, args)) kern = place_packed16_kernel<BITS, TM, U, PU>;
+        if (use_pipelined16(db, g, args)) {
+            kern = place_packed16_kernel<BITS, TM, U, PU>;
+            if constexpr (BITS == 5) {
+                // every read of the batch has the same, known length and at most 96 k-mers (C4: 100 residues, k = 5): six rounds
+                if (!args.lens && args.fixed_len >= db->info.k && args.fixed_len - db->info.k + 1 <= 96u) kern = place_packed16_kernel<BITS, TM, U, 6>;
+            }
+        }
     }
     const uint32_t wpb = db->waves_per_block;
     const size_t lds = g.lds_per_wave * wpb;
