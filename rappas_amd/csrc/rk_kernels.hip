@@ -794,6 +794,11 @@ __device__ __forceinline__ void heads_scan_reset(u32 *S, u32 n_branches, u32 li,
     heads_scan<G, true>(S, n_branches + 1, li, slot_base, h);  // (a tile in doubt is accumulated again from its lists, not from S)
 }
 
+template <int LANE>
+__device__ __forceinline__ u32 row_bcast32(u32 v) {  // value of lane LANE of the caller's 16-lane row
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + LANE, 0xF, 0xF, false);  // row_newbcast:LANE
+}
+
 // LWR + keep-factor + output rows for one read.  Called by all lanes of the group (li = lane in group).
 // Requires G >= keep_at_most.
 template <int G>
@@ -806,25 +811,56 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
     double lwr = 0.0;
     if (numBest > 0 && !(RK_ABLATE & 4)) {
         flags |= RK_FLAG_PLACED;
-        float best = __shfl(score, 0, G);
-        float lowest = __shfl(score, numBest - 1, G);
+        const bool mine = (int)li < numBest;
+        float best, lowest;
+        if (G == 16) {  // a group is one DPP row: no LDS round trips (the shuffles below are ds_bpermute + a wait each)
+            best = __uint_as_float(row_bcast32<0>(__float_as_uint(score)));
+            float lo = mine ? score : INFINITY;  // (the winners are in descending order: the last one is the smallest)
+            lo = fminf(lo, __uint_as_float(row_ror32<8>(__float_as_uint(lo))));
+            lo = fminf(lo, __uint_as_float(row_ror32<4>(__float_as_uint(lo))));
+            lo = fminf(lo, __uint_as_float(row_ror32<2>(__float_as_uint(lo))));
+            lowest = fminf(lo, __uint_as_float(row_ror32<1>(__float_as_uint(lo))));
+        } else {
+            best = __shfl(score, 0, G);
+            lowest = __shfl(score, numBest - 1, G);
+        }
         // computeWeightRatioShift (PlacementProcess.java:384-390); `lowest` starts at 0.0f in :413 and every
         // score is < 0 whenever the shift matters, so min(0, lowest) <= -308 <=> lowest <= -308.
         float lowest0 = lowest < 0.0f ? lowest : 0.0f;
         float shift = (-308.0f >= lowest0) ? best : 0.0f;
-        bool mine = (int)li < numBest;
         // :441-448  sum_{ascending} pow(10, (double)(float)(score - shift));  (:418 sums in heap order when
         // shift == 0 -- same terms, order differs only in the last ulp of a double)
         float d32 = score - shift;
         double term = mine ? exp10((double)d32) : 0.0;
         double sum = 0.0;
-        for (int q = numBest - 1; q >= 0; q--) sum += shfl_f64(term, q, G);
+        if (G == 16) {
+            // the same additions in the same order as the loop of the other branch -- t[n-1] + t[n-2] + ... + t[0], the terms beyond
+            // the winners being 0.0 -- as a chain over the row: acc(i) = t(i) + acc(i + 1), K - 1 times; lane 0 ends with the sum
+            auto shl1 = [](double v) {  // value of the next lane of the row (0.0 behind its last lane)
+                const u64 b = (u64)__double_as_longlong(v);
+                const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x101, 0xF, 0xF, true);
+                const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x101, 0xF, 0xF, true);
+                return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+            };
+            double acc = term;
+            for (int s_ = 1; s_ < K; s_++) acc = term + shl1(acc);
+            const u64 ab = (u64)__double_as_longlong(acc);
+            sum = __longlong_as_double((long long)(((u64)row_bcast32<0>((u32)(ab >> 32)) << 32) | row_bcast32<0>((u32)ab)));
+        } else {
+            for (int q = numBest - 1; q >= 0; q--) sum += shfl_f64(term, q, G);
+        }
         float shift2 = (-308.0f >= lowest) ? best : 0.0f;  // :978-980 uses the true minimum
         // :392-394 Math.pow(10.0, (double)score - (double)shift2): the same number as `term` unless a shift is in play
         double numer = term;
         if (__any(shift != 0.0f || shift2 != 0.0f)) numer = mine ? exp10((double)score - (double)shift2) : 0.0;
         double ratio = mine ? numer / sum : 0.0;
-        double best_ratio = shfl_f64(ratio, 0, G);
+        double best_ratio;
+        if (G == 16) {
+            const u64 rb = (u64)__double_as_longlong(ratio);
+            best_ratio = __longlong_as_double((long long)(((u64)row_bcast32<0>((u32)(rb >> 32)) << 32) | row_bcast32<0>((u32)rb)));
+        } else {
+            best_ratio = shfl_f64(ratio, 0, G);
+        }
         bool fail = mine && li > 0 && (ratio < best_ratio * (double)a.keep_factor);  // :998-1000
         u64 fb = __ballot(fail);
         u32 lane = threadIdx.x & 63;
@@ -1115,11 +1151,6 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
 //     instead of relying on another wave's row gathers to fill it.
 // Results are identical to place_packed_kernel's (same emit order, same accumulate, same select).
 // ------------------------------------------------------------------------------------------------
-template <int LANE>
-__device__ __forceinline__ u32 row_bcast32(u32 v) {  // value of lane LANE of the caller's 16-lane row
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + LANE, 0xF, 0xF, false);  // row_newbcast:LANE
-}
-
 template <int PU, int U0>
 struct Batch0Words {
     static __device__ __forceinline__ void run(u32 recw, u32 (&w)[PU + 1]) {
