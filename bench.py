@@ -598,6 +598,15 @@ def main():
             "verified_vs_oracle": verified,
         }
         line.update(per_rank_fields(sync, per_rank))
+        pinned_bufs = None
+        if not a.no_pcie and n_gpus == 1:
+            # the page-locked caller buffers of the boundary legs below, allocated here, as a caller would at start-up.  (Allocated after
+            # the clade leg -- seconds of numpy on the host in between -- the same leg ran at 1.0 - 1.9e8 reads/s instead of 3.0e8, five
+            # runs of five: wherever the thread was by then, its page-locked memory landed further from the GPU.)
+            npc_ = min(a.pcie_reads, n_reads)
+            pinned_bufs = (ra.host_alloc((npc_, wpr), np.uint32),
+                           ra.Placements(ra.host_alloc(npc_, np.uint8), ra.host_alloc((npc_, K), np.uint16), ra.host_alloc((npc_, K), np.float32),
+                                         ra.host_alloc((npc_, K), np.float64), ra.host_alloc(npc_, np.uint32), {}))
         if a.config == "C2" and not a.no_clade and n_gpus == 1:
             # ---- the same tree and row statistics with clade-shaped reads (what real placements look like): never `value` ----
             cdb_s, genome = synth.make_clade_db(k=k, n_branches=n_branches)
@@ -650,10 +659,8 @@ def main():
             same = bool(np.array_equal(reuse.n_rows, dev_n) and np.array_equal(reuse.branch, out["branch"][:npc].cpu().numpy().view(np.uint16)))
             r_ascii = timed(lambda: pp.processQueries(h_seq, h_off, keepAtMost=K, out=reuse))
             # the same with page-locked caller buffers (rk_host_alloc; a JVM wraps them as direct ByteBuffers): no staging copies
-            p_packed = ra.host_alloc(h_packed.shape, np.uint32)
+            p_packed, p_out = pinned_bufs
             p_packed[:] = h_packed
-            p_out = ra.Placements(ra.host_alloc(npc, np.uint8), ra.host_alloc((npc, K), np.uint16), ra.host_alloc((npc, K), np.float32),
-                                  ra.host_alloc((npc, K), np.float64), ra.host_alloc(npc, np.uint32), {})
             r_pinned = timed(lambda: pp.processQueriesPacked(p_packed, fixed_len=rlen, keepAtMost=K, out=p_out))
             same = same and bool(np.array_equal(p_out.n_rows, dev_n))
             pk_out = pp.pack_reads_host(h_seq, h_off, max_len=rlen)           # (first call: the output pages are touched here)
