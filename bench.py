@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--verify", type=int, default=2000, help="reads checked against the oracle before timing")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-clade", action="store_true", help="C2 only: skip the clade-shaped variant of the line (reads cut from a genome whose k-mers "
+    ap.add_argument("--no-clade", action="store_true", help="C2 and T4k ... T64k: skip the clade-shaped variant of the line (reads cut from a genome whose k-mers "
                     "make up the database: the K best branches are neighbours, every k-mer is present)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (host buffers through rk_place_batch / rk_place_batch_packed)")
     ap.add_argument("--pcie-reads", type=int, default=4_000_000, help="reads of the PCIe-inclusive leg (rank 0, N=1)")
@@ -607,7 +607,7 @@ def main():
             pinned_bufs = (ra.host_alloc((npc_, wpr), np.uint32),
                            ra.Placements(ra.host_alloc(npc_, np.uint8), ra.host_alloc((npc_, K), np.uint16), ra.host_alloc((npc_, K), np.float32),
                                          ra.host_alloc((npc_, K), np.float64), ra.host_alloc(npc_, np.uint32), {}))
-        if a.config == "C2" and not a.no_clade and n_gpus == 1:
+        if a.config in ("C2", "T4k", "T8k", "T20k", "T64k") and not a.no_clade and n_gpus == 1:
             # ---- the same tree and row statistics with clade-shaped reads (what real placements look like): never `value` ----
             cdb_s, genome = synth.make_clade_db(k=k, n_branches=n_branches)
             nc = min(2_000_000, n_reads)
