@@ -1254,6 +1254,36 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     const uint32_t probe_cap = (db->info.bits_per_symbol == 5 ? 7u : 9u) * 16u;
     const bool one_batch = a.lens != nullptr || a.fixed_len < db->info.k || a.fixed_len - db->info.k + 1 <= probe_cap;
     const bool sorted_first = a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
+    // ---- tiles of reads that hit the same windows (rk_kernels.hip: retile_*): keys, counting sort, the order the kernels take their
+    //      tiles in.  Scratch is the stream's own (allocated and freed in stream order); without it the batch keeps its order ----
+    struct Scratch {
+        void *p = nullptr;
+        hipStream_t s;
+        explicit Scratch(hipStream_t st) : s(st) {}
+        ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
+    } scratch(stream);
+    a.perm = nullptr;
+    uint64_t retile_min = 32768;  // (below, the pre-pass's three launches cost more than they can win)
+    if (const char *e = rk_knob("RK_RETILE_MIN_READS")) retile_min = (uint64_t)atoll(e);  // developer / test knob (0 = always)
+    if (a.n_reads >= retile_min && a.n_reads < (1ull << 32) && !rk_knob("RK_NO_RETILE")) {
+        const size_t perm_off = 1024, keys_off = perm_off + (((size_t)a.n_reads * 4 + 255) & ~(size_t)255), total = keys_off + a.n_reads;
+        if (hipMallocAsync(&scratch.p, total, stream) == hipSuccess && scratch.p) {
+            unsigned char *base = (unsigned char *)scratch.p;
+            uint32_t *hist = (uint32_t *)base, *cursor = hist + 128, *perm = (uint32_t *)(base + perm_off);
+            unsigned char *keys = base + keys_off;
+            HIP_TRY(hipMemsetAsync(base, 0, perm_off, stream));
+            const unsigned nblk = (unsigned)((a.n_reads + 255) / 256);
+            if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_key_kernel<2>, dim3(nblk), dim3(256), 0, stream, a, keys, hist);
+            else hipLaunchKernelGGL(retile_key_kernel<5>, dim3(nblk), dim3(256), 0, stream, a, keys, hist);
+            hipLaunchKernelGGL(retile_scan_kernel, dim3(1), dim3(64), 0, stream, a.n_reads, hist, cursor);
+            hipLaunchKernelGGL(retile_scatter_kernel, dim3(nblk), dim3(256), 0, stream, a.n_reads, (const unsigned char *)keys, (const uint32_t *)hist, cursor, perm);
+            HIP_TRY(hipGetLastError());
+            a.perm = perm;
+        } else {
+            (void)hipGetLastError();
+            scratch.p = nullptr;
+        }
+    }
     if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of

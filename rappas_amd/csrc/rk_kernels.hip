@@ -1443,6 +1443,83 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // A row that straddles windows is read once per window it touches (rows are mostly runs of neighbouring branches: rare).
 // Reads whose items do not fit the main list fall back to probing the read once per window (row descriptors + row cursor).
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Tiles of reads that hit the same windows (round 3).  The windowed kernels walk a tile's four reads window by window in step; the
+// reads of a real batch sit each in its own clade -- one or two windows, another one for every read -- so that a window has one of the
+// four at work (scripts/clade_bench.py: 41 against 102 Mreads/s on uniform reads at 19 999 branches).  Before such a launch every read
+// gets a key -- the middle one of the first windows of the rows of its first, middle and last k-mer -- and a counting sort by key gives the
+// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads have no two of the three within a window of each
+// other (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
+
+constexpr int RETILE_BINS = 64;
+// hist[0..63]: reads per key; hist[64]: reads none of whose sampled k-mers agree; hist[65]: 1 = keep the order
+template <int BITS>
+__global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned char *keys, u32 *hist) {
+    __shared__ u32 h[RETILE_BINS + 1];
+    if (threadIdx.x <= RETILE_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < a.n_reads) {
+        const u32 k = a.db.k, wpr = a.words_per_read;
+        u32 R = a.lens ? a.lens[r] : a.fixed_len;
+        const u32 cap_syms = (wpr * 32u) / BITS;
+        R = R < cap_syms ? R : cap_syms;
+        const u32 fin = a.flags_in ? a.flags_in[r] : 0u;
+        const bool plain = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG)) == 0 && R >= k;
+        u32 key = 0, spread = 0;
+        if (plain) {
+            const u32 Q = R - k + 1;
+            const u32 *rec = a.packed + r * wpr;
+            const u32 pos[3] = {0u, Q / 2, Q - 1};
+            u32 w[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, pos[i], k), k)] & 63u;
+            // the middle one of the three: a k-mer that also occurs elsewhere in the reference (its row is filed under another clade)
+            // does not move the key as long as the other two agree
+            const u32 lo = min(min(w[0], w[1]), w[2]), hi = max(max(w[0], w[1]), w[2]), mid = w[0] + w[1] + w[2] - lo - hi;
+            key = mid;
+            spread = min(mid - lo, hi - mid) > 1u ? 1u : 0u;  // no two of them within a window of each other
+        }
+        keys[r] = (unsigned char)key;
+        atomicAdd(&h[key], 1u);
+        if (spread) atomicAdd(&h[RETILE_BINS], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= RETILE_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// one block: start of every key's range (cursor[0..63]), and whether the batch is re-tiled at all
+__global__ void __launch_bounds__(64) retile_scan_kernel(u64 n_reads, u32 *hist, u32 *cursor) {
+    const u32 t = threadIdx.x;
+    u32 v = hist[t], incl = v;
+    for (int s = 1; s < 64; s <<= 1) {
+        const u32 o = (u32)__shfl_up((int)incl, s, 64);
+        if ((int)t >= s) incl += o;
+    }
+    cursor[t] = incl - v;
+    if (t == 0) hist[RETILE_BINS + 1] = ((u64)hist[RETILE_BINS] * 2 > n_reads) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) retile_scatter_kernel(u64 n_reads, const unsigned char *keys, const u32 *hist, u32 *cursor, u32 *perm) {
+    __shared__ u32 cnt[RETILE_BINS], base[RETILE_BINS];
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hist[RETILE_BINS + 1]) {  // (block-uniform) the batch keeps its order
+        if (r < n_reads) perm[r] = (u32)r;
+        return;
+    }
+    if (threadIdx.x < RETILE_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    u32 key = 0, rank = 0;
+    if (r < n_reads) {
+        key = keys[r];
+        rank = atomicAdd(&cnt[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < RETILE_BINS && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+    if (r < n_reads) perm[base[key] + rank] = (u32)r;
+}
+
 template <int BITS, int U, int PU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16w_kernel(PlaceArgs a) {  // (amino acids: 286 registers left to itself = one wave per SIMD; DNA: 219, and slower when asked for two)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT;
@@ -1480,8 +1557,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     const u64 wave_count = (u64)gridDim.x * waves_per_block;
 
     auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
-        const u64 r = tile * NG + gi;
-        have = tile < n_tiles && r < a.n_reads;
+        const u64 slot = tile * NG + gi;
+        have = tile < n_tiles && slot < a.n_reads;
+        const u64 r = have ? tile_read(a, slot) : 0ull;
         recw = 0; R = 0; fin = 0;
         if (have) {
             if (li < wpr) recw = a.packed[r * wpr + li];
@@ -1544,15 +1622,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         if (a.only_marked) {  // second launch behind place_packed16s_kernel: only the tiles it handed over (their first read's flag word)
-            const u32 mark = a.o_flags[tile * NG] & RK_FLAG_INTERNAL_DEFERRED;
+            const u32 mark = a.o_flags[tile_read(a, tile * NG)] & RK_FLAG_INTERNAL_DEFERRED;
             if (!__builtin_amdgcn_readfirstlane((int)mark)) {
                 load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
                 continue;
             }
         }
-        const u64 r = tile * NG + gi;
         const bool have = c_have;
-        c_rec = a.packed + (have ? r : 0ull) * wpr;
+        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
+        c_rec = a.packed + r * wpr;
         const u32 fin = c_fin;
         u32 R = c_R;
         {
@@ -1867,8 +1945,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     const u64 wave_count = (u64)gridDim.x * waves_per_block;
 
     auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
-        const u64 r = tile * NG + gi;
-        have = tile < n_tiles && r < a.n_reads;
+        const u64 slot = tile * NG + gi;
+        have = tile < n_tiles && slot < a.n_reads;
+        const u64 r = have ? tile_read(a, slot) : 0ull;
         recw = 0; R = 0; fin = 0;
         if (have) {
             if (li < wpr) recw = a.packed[r * wpr + li];
@@ -1895,8 +1974,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     load_tile(wave_global, c_recw, c_R, c_fin, c_have);
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
-        const u64 r = tile * NG + gi;
         const bool have = c_have;
+        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
         const u32 fin = c_fin, recw = c_recw;
         u32 R = c_R;
         {
@@ -1982,7 +2061,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #ifdef RK_STAMPS
             st_[10] += 1;
 #endif
-            if (lane == 0) a.o_flags[tile * NG] = RK_FLAG_INTERNAL_DEFERRED;
+            if (lane == 0) a.o_flags[tile_read(a, tile * NG)] = RK_FLAG_INTERNAL_DEFERRED;
             wave_lds_fence();
             continue;
         }
@@ -2290,7 +2369,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             }
         }
         if (__any(cand_over)) {  // (wave-uniform) rare twice over: the tile is left to place_packed16w_kernel; S is in its reset state
-            if (lane == 0) a.o_flags[tile * NG] = RK_FLAG_INTERNAL_DEFERRED;
+            if (lane == 0) a.o_flags[tile_read(a, tile * NG)] = RK_FLAG_INTERNAL_DEFERRED;
 #ifdef RK_STAMPS
             st_[10] += 1;
 #endif

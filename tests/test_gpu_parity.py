@@ -722,6 +722,29 @@ def test_best_branches_that_are_neighbours(n_branches, K):
             run_case(sdb, odb, seq, off, "direct", lanes, "mean", keepAtMost=K, keepFactor=0.0)
 
 
+@pytest.mark.parametrize("n_branches", [3999, 9001, 20001, 65535])
+def test_tiles_of_reads_that_hit_the_same_windows(n_branches, monkeypatch, dev_lib):
+    """the windowed kernels take their tiles through the order a counting sort by window gives (PlaceArgs::perm; batches of 32 768 reads
+    and more in the product, every batch here): clade-shaped reads -- re-tiled -- mixed with uniform ones, ragged lengths, ambiguity
+    codes and unsupported characters (reads the ASCII kernel or nobody places keep their own index too), a batch that is not a
+    multiple of four, and a batch of uniform reads alone (the order is kept)"""
+    monkeypatch.setenv("RK_RETILE_MIN_READS", "0")
+    sdb, genome = _clade_db(9, n_branches, 6000, seed=n_branches)
+    odb = O.OracleDB.from_synth(sdb)
+    s1, o1 = synth.make_motif_reads(genome, 2501, 150, seed=5, amb_rate=0.001, var_len=40)
+    s2, o2 = synth.make_reads(4, 700, 150, seed=6, amb_rate=0.001, bad_rate=0.01, var_len=100)
+    seq = np.concatenate([s1, s2])
+    off = np.concatenate([o1, o2[1:] + o1[-1]])
+    perm = np.random.default_rng(n_branches).permutation(len(off) - 1)  # clade and uniform reads interleaved
+    lens = np.diff(off.astype(np.int64))
+    new_off = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.uint64)
+    new_seq = np.concatenate([seq[int(off[i]):int(off[i + 1])] for i in perm])
+    for K, amb in ((7, "mean"), (16, "skip")):
+        _, _, st = run_case(sdb, odb, new_seq, new_off, "direct", 0, amb, keepAtMost=K)
+        assert st["placed"] > 2400
+    run_case(sdb, odb, s2, o2, "direct", 0, "mean")
+
+
 def test_windowed_kernel_rows_scattered_over_all_windows():
     sdb = _scatter_rows(synth.make_db(4, 7, 5000, 12000, 150000, seed=9), seed=10)
     seq, off = synth.make_reads(4, 1500, 150, seed=3, amb_rate=0.001)
