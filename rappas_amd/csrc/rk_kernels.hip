@@ -1447,9 +1447,9 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // Tiles of reads that hit the same windows (round 3).  The windowed kernels walk a tile's four reads window by window in step; the
 // reads of a real batch sit each in its own clade -- one or two windows, another one for every read -- so that a window has one of the
 // four at work (scripts/clade_bench.py: 41 against 102 Mreads/s on uniform reads at 19 999 branches).  Before such a launch every read
-// gets a key -- the middle one of the first windows of the rows of its first, middle and last k-mer -- and a counting sort by key gives the
-// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads have no two of the three within a window of each
-// other (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
+// gets a key -- the middle one of the first windows of the rows of five of its k-mers -- and a counting sort by key gives the
+// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads' middle three are windows apart
+// (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
 
@@ -1472,15 +1472,16 @@ __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned c
         if (plain) {
             const u32 Q = R - k + 1;
             const u32 *rec = a.packed + r * wpr;
-            const u32 pos[3] = {0u, Q / 2, Q - 1};
-            u32 w[3];
+            const u32 pos[5] = {0u, Q / 4, Q / 2, (3 * Q) / 4, Q - 1};
+            u32 w[5];
 #pragma unroll
-            for (int i = 0; i < 3; i++) w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, pos[i], k), k)] & 63u;
-            // the middle one of the three: a k-mer that also occurs elsewhere in the reference (its row is filed under another clade)
-            // does not move the key as long as the other two agree
-            const u32 lo = min(min(w[0], w[1]), w[2]), hi = max(max(w[0], w[1]), w[2]), mid = w[0] + w[1] + w[2] - lo - hi;
-            key = mid;
-            spread = min(mid - lo, hi - mid) > 1u ? 1u : 0u;  // no two of them within a window of each other
+            for (int i = 0; i < 5; i++) w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, pos[i], k), k)] & 63u;
+            // the middle one of the five: k-mers that also occur elsewhere in the reference (their rows are filed under another clade), or
+            // that every clade shares, do not move the key as long as three of the five agree
+            auto cx = [](u32 &x, u32 &y) { const u32 lo_ = min(x, y), hi_ = max(x, y); x = lo_; y = hi_; };
+            cx(w[0], w[1]); cx(w[3], w[4]); cx(w[2], w[4]); cx(w[2], w[3]); cx(w[0], w[3]); cx(w[0], w[2]); cx(w[1], w[4]); cx(w[1], w[3]); cx(w[1], w[2]);
+            key = w[2];
+            spread = (w[3] - w[1] > 2u) ? 1u : 0u;  // the middle three are not within a window or two of each other
         }
         keys[r] = (unsigned char)key;
         atomicAdd(&h[key], 1u);
