@@ -1902,15 +1902,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 //     order -- LDS operations of a wave execute in program order -- gives every row its place);
 //   * one continuous accumulate stream over that list: the register ring of row loads runs across window boundaries (no pipeline
 //     fill per window), the window filter is applied when an entry's step comes;
-//   * at a first touch (the lane sees the untouched marker) the slot is appended to the read's TOUCHED list; at a window boundary
-//     only those slots are read into the stream heads and reset -- nothing is scanned, nothing is compacted.  (A window that
-//     overflows the touched list is scanned whole.)  Stream heads fed in any slot order keep the slot itself; a value that ties
-//     with a kept one raises the tile's doubt flag like a dropped candidate does, and the tile is redone with the exact select of
-//     every window, as in place_packed16w_kernel.
+//   * every slot of S starts from the read's Q * T, a step adds (score - T) to its slot (read + add + write: the LDS float atomic is
+//     serialised lane by lane on gfx950) and ORs the slot's bit into the window's TOUCHED bitmap (integer LDS atomic, full rate; slot
+//     s -> bit s >> 4 of lane s & 15); at a window boundary a lane takes its mask's slots four at a time into the stream heads and
+//     restores Q * T -- nothing is scanned, nothing is compacted.  Stream heads fed in any slot order keep the slot itself; equal
+//     scores inside a stream are read off the heads at the end (s0 == s1, or dr == s1) and, like a dropped candidate, put the tile in
+//     doubt if they could be among the K best: it then takes the stream a second time and ranks the few entries at or above the K-th
+//     score exactly.
 // Tiles that do not fit are marked (RK_FLAG_INTERNAL_DEFERRED in their first read's flag word) and placed by
 // place_packed16w_kernel, launched behind this kernel with only_marked set.  Results are identical to the dense kernels'.
-// LDS per read: S[s_stride] | list[main_cap] | touched[work_cap words = 2 * work_cap u16 slots; also the counters of the emit and
-// the scratch of the exact select].
+// LDS per read: S[s_stride: 16 scratch words, one per lane, then the window's slots] | list[main_cap] | work[work_cap words: the 64
+// window counters and the 16 idle words of the emit; the bitmap of the stream (16 or 32 words); the 48 keys of the second pass].
+// DESIGN.md section 4.1c has the measurements and what was tried.
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int U, int PU, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16s_kernel(PlaceArgs a) {  // (amino acids: 264 registers left to itself, one wave per SIMD)
@@ -1924,11 +1927,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     u32 *wbase = lds + wave * wave_words;
     u32 *S = wbase + gi * a.s_stride;
     u32 *items = wbase + NG * a.s_stride + gi * a.main_cap;
-    u32 *tlw = wbase + NG * (a.s_stride + a.main_cap) + gi * a.work_cap;  // counters (emit) / touched slots (stream) / u64 scratch (exact select)
-    unsigned short *tl = (unsigned short *)tlw;
+    u32 *tlw = wbase + NG * (a.s_stride + a.main_cap) + gi * a.work_cap;  // counters + idle words (emit) / touched bitmap (stream) / u64 scratch (second pass)
     u64 *work64 = (u64 *)tlw;
     const u32 nb = a.db.n_branches, k = a.db.k;
-    const u32 W = a.db.win_w, NWIN = a.db.n_win;
+    const u32 W = a.db.win_w;
     const float T = a.db.T;
     const int K = (int)a.keep_at_most;
     const u64 gmask = (1ull << G) - 1;
@@ -1962,12 +1964,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
         v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
         v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
         return v;
-    };
-    auto wave_max4 = [](int v) {  // largest value among the wave's four groups (v is group-uniform)
-        int m = __builtin_amdgcn_readlane(v, 0);
-        m = max(m, __builtin_amdgcn_readlane(v, 16));
-        m = max(m, __builtin_amdgcn_readlane(v, 32));
-        return max(m, __builtin_amdgcn_readlane(v, 48));
     };
 
     u32 c_recw, c_R, c_fin;
