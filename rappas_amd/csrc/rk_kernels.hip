@@ -1447,14 +1447,14 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // Tiles of reads that hit the same windows (round 3).  The windowed kernels walk a tile's four reads window by window in step; the
 // reads of a real batch sit each in its own clade -- one or two windows, another one for every read -- so that a window has one of the
 // four at work (scripts/clade_bench.py: 41 against 102 Mreads/s on uniform reads at 19 999 branches).  Before such a launch every read
-// gets a key -- the middle one of the first windows of the rows of five of its k-mers -- and a counting sort by key gives the
-// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads' middle three are windows apart
-// (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
+// gets a key -- the first window most of the rows of five of its k-mers agree on -- and a counting sort by key gives the
+// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads have no three of the five within a window
+// of each other (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
 
 constexpr int RETILE_BINS = 64;
-// hist[0..63]: reads per key; hist[64]: reads none of whose sampled k-mers agree; hist[65]: 1 = keep the order
+// hist[0..63]: reads per key; hist[64]: reads without three sampled k-mers that agree; hist[65]: 1 = keep the order
 template <int BITS>
 __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned char *keys, u32 *hist) {
     __shared__ u32 h[RETILE_BINS + 1];
@@ -1476,12 +1476,19 @@ __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned c
             u32 w[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, pos[i], k), k)] & 63u;
-            // the middle one of the five: k-mers that also occur elsewhere in the reference (their rows are filed under another clade), or
-            // that every clade shares, do not move the key as long as three of the five agree
-            auto cx = [](u32 &x, u32 &y) { const u32 lo_ = min(x, y), hi_ = max(x, y); x = lo_; y = hi_; };
-            cx(w[0], w[1]); cx(w[3], w[4]); cx(w[2], w[4]); cx(w[2], w[3]); cx(w[0], w[3]); cx(w[0], w[2]); cx(w[1], w[4]); cx(w[1], w[3]); cx(w[1], w[2]);
-            key = w[2];
-            spread = (w[3] - w[1] > 2u) ? 1u : 0u;  // the middle three are not within a window or two of each other
+            // the window most of the five agree on (to within one): k-mers that also occur elsewhere in the reference (their rows are
+            // filed under another clade), or that every clade shares, do not move the key while two or three of the five are at home
+            u32 best = 0, best_n = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                u32 n_ = 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) n_ += (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u ? 1u : 0u;
+                best = n_ > best_n ? w[i] : best;
+                best_n = max(best_n, n_);
+            }
+            key = best;
+            spread = best_n < 3u ? 1u : 0u;  // no three of them within a window of each other: a read without a clade (uniform reads)
         }
         keys[r] = (unsigned char)key;
         atomicAdd(&h[key], 1u);
