@@ -1447,8 +1447,8 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // Tiles of reads that hit the same windows (round 3).  The windowed kernels walk a tile's four reads window by window in step; the
 // reads of a real batch sit each in its own clade -- one or two windows, another one for every read -- so that a window has one of the
 // four at work (scripts/clade_bench.py: 41 against 102 Mreads/s on uniform reads at 19 999 branches).  Before such a launch every read
-// gets a key -- the first window most of the rows of five of its k-mers agree on -- and a counting sort by key gives the
-// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads have no three of the five within a window
+// gets a key -- the first window most of the rows of seven of its k-mers agree on -- and a counting sort by key gives the
+// order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads have no three of the seven within a window
 // of each other (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
@@ -1472,18 +1472,21 @@ __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned c
         if (plain) {
             const u32 Q = R - k + 1;
             const u32 *rec = a.packed + r * wpr;
-            const u32 pos[5] = {0u, Q / 4, Q / 2, (3 * Q) / 4, Q - 1};
-            u32 w[5];
+            constexpr int NS = 7;
+            u32 w[NS];
 #pragma unroll
-            for (int i = 0; i < 5; i++) w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, pos[i], k), k)] & 63u;
-            // the window most of the five agree on (to within one): k-mers that also occur elsewhere in the reference (their rows are
-            // filed under another clade), or that every clade shares, do not move the key while two or three of the five are at home
+            for (int i = 0; i < NS; i++) {
+                const u32 p_ = (u32)(((u64)(Q - 1) * (u32)i) / (NS - 1));
+                w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, p_, k), k)] & 63u;
+            }
+            // the window most of the seven agree on (to within one): k-mers that also occur elsewhere in the reference (their rows are
+            // filed under another clade), or that every clade shares, do not move the key while a few of the seven are at home
             u32 best = 0, best_n = 0;
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
+            for (int i = 0; i < NS; i++) {
                 u32 n_ = 0;
 #pragma unroll
-                for (int j = 0; j < 5; j++) n_ += (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u ? 1u : 0u;
+                for (int j = 0; j < NS; j++) n_ += (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u ? 1u : 0u;
                 best = n_ > best_n ? w[i] : best;
                 best_n = max(best_n, n_);
             }
