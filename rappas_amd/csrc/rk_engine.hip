@@ -455,6 +455,7 @@ struct rk_db {
     unsigned char *d_alpha = nullptr;  // table[256] | alts[320] | alt_count[16]
     unsigned char *d_winspec = nullptr;  // [sigma^k] window span per k-mer (windowed images only)
     bool windowed = false;
+    bool has_pos = false;              // d_winspec holds position keys only (dense kernels)
     bool compact_nib = false;          // the compact table holds 4-bit unit counts
     WindowPlan wp;
     uint32_t lanes_per_read = 0;       // 0 = auto
@@ -563,7 +564,7 @@ static void finish_db(rk_db *db, const DbMeta &m, uint32_t mode, bool indexed, b
     db->view.T = m.thr_log10; db->view.P = m.thr; db->view.convert_uo = m.convert_uo;
     db->view.soa = indexed ? 1u : 0u;
     db->view.mono = mono ? 1u : 0u;
-    db->view.winspec = db->windowed ? db->d_winspec : nullptr;
+    db->view.winspec = (db->windowed || db->has_pos) ? db->d_winspec : nullptr;
     db->view.win_w = db->windowed ? db->wp.W : 0u;
     db->view.n_win = db->windowed ? db->wp.n_win : 0u;
 }
@@ -644,6 +645,7 @@ struct DbImage {
     std::vector<uint64_t> table;
     bool nib = false;                   // compact table in its 4-bit form
     bool windowed = false;              // place_packed16w_kernel can serve this image
+    bool has_pos = false;               // not windowed, but winspec holds the rows' position in the tree (64 ranges): the key reads are grouped by
     WindowPlan wp;
     std::vector<unsigned char> winspec;  // [sigma^k]
 };
@@ -739,8 +741,13 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
     std::vector<uint64_t> desc(n_keys);  // by key number
     WindowPlan wp;
     const bool want_windows = kind.windowable && window_plan(d->n_branches, bits, space ? (double)slot_units / (double)space : 0.0, mean_len / ROW_UNIT + 0.5, wp);
+    // Images the dense kernels serve get the same byte per k-mer code with the tree cut into 64 equal ranges: not for any window
+    // -- the kernels hold the whole score vector -- but as the position a batch's reads are grouped by (reads of one clade read the
+    // same rows: taken together they find them in the L2; scripts/clade_sorted_probe.py: 283 -> 406 Mreads/s on C2's shape)
+    const bool want_pos = !want_windows && !indexed && space_ok && space <= (1ull << 26);
+    const uint32_t key_w = want_windows ? wp.W : std::max<uint32_t>(1u, (d->n_branches + 63u) / 64u);
     std::vector<unsigned char> ws_by_key;  // winspec_byte(first window, last window) of every row
-    if (want_windows) {
+    if (want_windows || want_pos) {
         try { ws_by_key.assign(n_keys, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
     }
     // slot-offset images: 128-byte units (ROW_UNIT = 16 entries), so a chunk of 16 entries is ONE aligned 128-byte request;
@@ -799,7 +806,7 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
                     ep[i].branch = indexed ? (uint32_t)x : ((uint32_t)x + 1u) * 4u;  // raw id (sorted, SoA below) | slot byte offset
                     ep[i].score = v;
                 }
-                if (want_windows) ws_by_key[r] = winspec_byte(xmin / wp.W, xmax / wp.W);
+                if (want_windows || want_pos) ws_by_key[r] = winspec_byte(xmin / key_w, xmax / key_w);
                 if (indexed) {
                     std::sort(ep, ep + len, [](const Entry &p, const Entry &q) { return p.branch < q.branch; });
                     unsigned char *row = (unsigned char *)(blob.data() + (desc[r] >> DESC_LEN_BITS));
@@ -865,6 +872,10 @@ static int build_image(const rk_db_desc *d, DbImage &img) {
         for (uint64_t i = 0; i < n_keys; i++) img.winspec[order[i].first] = ws_by_key[order[i].second];
         img.windowed = true;
         img.wp = wp;
+    } else if ((want_windows || want_pos) && (img.mode == RK_TABLE_DIRECT || img.mode == RK_TABLE_DIRECT8)) {
+        try { img.winspec.assign(space, 0); } catch (const std::bad_alloc &) { return fail(RK_ERR_NOMEM, "rk_db_create: host OOM"); }
+        for (uint64_t i = 0; i < n_keys; i++) img.winspec[order[i].first] = ws_by_key[order[i].second];
+        img.has_pos = true;
     }
     return RK_OK;
 }
@@ -922,11 +933,12 @@ extern "C" int rk_db_create(const rk_db_desc *d, rk_db **out) {
     DB_TRY(hipMalloc(&db->d_rows, blob_bytes));
     if (table_bytes) DB_TRY(hipMemcpy(db->d_table, table.data(), table_bytes, hipMemcpyHostToDevice));
     DB_TRY(hipMemcpy(db->d_rows, blob.data(), blob_bytes, hipMemcpyHostToDevice));
-    if (img.windowed) {
+    if (img.windowed || img.has_pos) {
         DB_TRY(hipMalloc((void **)&db->d_winspec, img.winspec.size()));
         DB_TRY(hipMemcpy(db->d_winspec, img.winspec.data(), img.winspec.size(), hipMemcpyHostToDevice));
-        db->windowed = true;
-        db->wp = img.wp;
+        db->windowed = img.windowed;
+        db->has_pos = img.has_pos;
+        if (img.windowed) db->wp = img.wp;
     }
 #undef DB_TRY
     db->compact_nib = img.nib;
@@ -969,12 +981,13 @@ extern "C" int rk_db_clone(const rk_db *src, int32_t device, rk_db **out) {
     CL_TRY(hipMalloc(&db->d_rows, blob_bytes));
     if (table_bytes) CL_TRY(copy(db->d_table, src->d_table, table_bytes));
     CL_TRY(copy(db->d_rows, src->d_rows, blob_bytes));
-    if (src->windowed) {
+    if (src->windowed || src->has_pos) {
         uint64_t space = 0;
         (void)ipow_fits(src->info.alphabet, src->info.k, 1ull << 40, space);
         CL_TRY(hipMalloc((void **)&db->d_winspec, space));
         CL_TRY(copy(db->d_winspec, src->d_winspec, space));
-        db->windowed = true;
+        db->windowed = src->windowed;
+        db->has_pos = src->has_pos;
         db->wp = src->wp;
     }
     CL_TRY(hipDeviceSynchronize());
@@ -1242,6 +1255,47 @@ static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_
     return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && fits;
 }
 
+// ---- tiles of reads that sit in the same part of the tree (rk_kernels.hip: retile_*): keys, counting sort, the order the kernels take
+//      their tiles in (PlaceArgs::perm).  Scratch is the stream's own (allocated and freed in stream order); without it, or below
+//      32 768 reads (the pre-pass's three launches cost more than they can win), the batch keeps its order ----
+struct TileOrder {
+    void *p = nullptr;
+    hipStream_t s;
+    explicit TileOrder(hipStream_t st) : s(st) {}
+    ~TileOrder() { if (p) (void)hipFreeAsync(p, s); }
+    TileOrder(const TileOrder &) = delete;
+    TileOrder &operator=(const TileOrder &) = delete;
+    int prepare(const rk_db *db, PlaceArgs &a) {
+        a.perm = nullptr;
+        if (!db->view.winspec) return RK_OK;  // (images without a position byte per k-mer: hashed tables, the large-tree image)
+        uint64_t retile_min = 32768;
+        if (const char *e = rk_knob("RK_RETILE_MIN_READS")) retile_min = (uint64_t)atoll(e);  // developer / test knob (0 = always)
+        if (a.n_reads < retile_min || a.n_reads >= (1ull << 32) || rk_knob("RK_NO_RETILE")) return RK_OK;
+        const size_t perm_off = 1024, keys_off = perm_off + (((size_t)a.n_reads * 4 + 255) & ~(size_t)255), total = keys_off + a.n_reads;
+        if (hipMallocAsync(&p, total, s) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return RK_OK;
+        }
+        unsigned char *base = (unsigned char *)p;
+        uint32_t *hist = (uint32_t *)base, *cursor = hist + 128, *perm = (uint32_t *)(base + perm_off);
+        unsigned char *keys = base + keys_off;
+        HIP_TRY(hipMemsetAsync(base, 0, perm_off, s));
+        const unsigned nblk = (unsigned)((a.n_reads + 255) / 256);
+        const unsigned sblk = (unsigned)((a.n_reads / 16 + 255) / 256 + 1);
+        if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_sample_kernel<2>, dim3(sblk), dim3(256), 0, s, a, hist);
+        else hipLaunchKernelGGL(retile_sample_kernel<5>, dim3(sblk), dim3(256), 0, s, a, hist);
+        hipLaunchKernelGGL(retile_decide_kernel, dim3(1), dim3(64), 0, s, hist);
+        if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_key_kernel<2>, dim3(nblk), dim3(256), 0, s, a, keys, hist);
+        else hipLaunchKernelGGL(retile_key_kernel<5>, dim3(nblk), dim3(256), 0, s, a, keys, hist);
+        hipLaunchKernelGGL(retile_scan_kernel, dim3(1), dim3(64), 0, s, hist, cursor);
+        hipLaunchKernelGGL(retile_scatter_kernel, dim3(nblk), dim3(256), 0, s, a.n_reads, (const unsigned char *)keys, (const uint32_t *)hist, cursor, perm);
+        HIP_TRY(hipGetLastError());
+        a.perm = perm;
+        return RK_OK;
+    }
+};
+
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     WindowPlan wp = db->wp;
     const uint64_t n_tiles = (a.n_reads + 3) / 4;
@@ -1254,36 +1308,8 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     const uint32_t probe_cap = (db->info.bits_per_symbol == 5 ? 7u : 9u) * 16u;
     const bool one_batch = a.lens != nullptr || a.fixed_len < db->info.k || a.fixed_len - db->info.k + 1 <= probe_cap;
     const bool sorted_first = a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
-    // ---- tiles of reads that hit the same windows (rk_kernels.hip: retile_*): keys, counting sort, the order the kernels take their
-    //      tiles in.  Scratch is the stream's own (allocated and freed in stream order); without it the batch keeps its order ----
-    struct Scratch {
-        void *p = nullptr;
-        hipStream_t s;
-        explicit Scratch(hipStream_t st) : s(st) {}
-        ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
-    } scratch(stream);
-    a.perm = nullptr;
-    uint64_t retile_min = 32768;  // (below, the pre-pass's three launches cost more than they can win)
-    if (const char *e = rk_knob("RK_RETILE_MIN_READS")) retile_min = (uint64_t)atoll(e);  // developer / test knob (0 = always)
-    if (a.n_reads >= retile_min && a.n_reads < (1ull << 32) && !rk_knob("RK_NO_RETILE")) {
-        const size_t perm_off = 1024, keys_off = perm_off + (((size_t)a.n_reads * 4 + 255) & ~(size_t)255), total = keys_off + a.n_reads;
-        if (hipMallocAsync(&scratch.p, total, stream) == hipSuccess && scratch.p) {
-            unsigned char *base = (unsigned char *)scratch.p;
-            uint32_t *hist = (uint32_t *)base, *cursor = hist + 128, *perm = (uint32_t *)(base + perm_off);
-            unsigned char *keys = base + keys_off;
-            HIP_TRY(hipMemsetAsync(base, 0, perm_off, stream));
-            const unsigned nblk = (unsigned)((a.n_reads + 255) / 256);
-            if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_key_kernel<2>, dim3(nblk), dim3(256), 0, stream, a, keys, hist);
-            else hipLaunchKernelGGL(retile_key_kernel<5>, dim3(nblk), dim3(256), 0, stream, a, keys, hist);
-            hipLaunchKernelGGL(retile_scan_kernel, dim3(1), dim3(64), 0, stream, a.n_reads, hist, cursor);
-            hipLaunchKernelGGL(retile_scatter_kernel, dim3(nblk), dim3(256), 0, stream, a.n_reads, (const unsigned char *)keys, (const uint32_t *)hist, cursor, perm);
-            HIP_TRY(hipGetLastError());
-            a.perm = perm;
-        } else {
-            (void)hipGetLastError();
-            scratch.p = nullptr;
-        }
-    }
+    TileOrder order(stream);
+    if (int rc = order.prepare(db, a)) return rc;
     if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
@@ -1362,7 +1388,11 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     return RK_OK;
 }
 
-static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a, hipStream_t s) {
+static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a_in, hipStream_t s) {
+    // (reads of one clade read the same rows: taken together they find them in the L2 -- scripts/clade_sorted_probe.py)
+    PlaceArgs a = a_in;
+    TileOrder order(s);
+    if (int rc = order.prepare(db, a)) return rc;
     switch (g.G) {
     case 8: return launch_b<8>(db, g, a, s);
     case 16: return launch_b<16>(db, g, a, s);

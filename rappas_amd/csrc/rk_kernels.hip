@@ -84,6 +84,8 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m, int width) {
 __device__ __forceinline__ double shfl_f64(double v, int src, int width) {
     return __longlong_as_double((long long)shfl64((u64)__double_as_longlong(v), src, width));
 }
+// the read a tile's slot stands for: PlaceArgs::perm when the batch's reads were grouped by their place in the tree (retile_* below)
+__device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
 // LDS data exchanged between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be stopped from reordering / caching.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -927,8 +929,8 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     unsigned long long t_ = rk_now();
 #endif
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
-        const u64 r = tile * NG + gi;
-        const bool have = r < a.n_reads;
+        const bool have = tile * NG + gi < a.n_reads;
+        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
         u32 R = 0, fin = 0;
         if (have) {
             R = a.lens ? a.lens[r] : a.fixed_len;
@@ -947,8 +949,8 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         // warm the cache with the NEXT tile's packed records (streamed from HBM, ~2 us if met cold by the probe)
         u32 warm = 0;
         {
-            const u64 rn = (tile + wave_count) * NG + gi;
-            if (rn < a.n_reads) warm = a.packed[rn * a.words_per_read + (li < a.words_per_read ? li : 0u)];
+            const u64 sn = (tile + wave_count) * NG + gi;
+            if (sn < a.n_reads) warm = a.packed[tile_read(a, sn) * a.words_per_read + (li < a.words_per_read ? li : 0u)];
         }
 
         u32 pos = 0;
@@ -1232,8 +1234,9 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 
     // per-tile inputs of a group: its record word, length, incoming flags
     auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
-        const u64 r = tile * NG + gi;
-        have = tile < n_tiles && r < a.n_reads;
+        const u64 slot = tile * NG + gi;
+        have = tile < n_tiles && slot < a.n_reads;
+        const u64 r = have ? tile_read(a, slot) : 0ull;
         recw = 0; R = 0; fin = 0;
         if (have) {
             if (li < wpr) recw = a.packed[r * wpr + li];
@@ -1280,8 +1283,8 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
     }
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
-        const u64 r = tile * NG + gi;
         const bool have = c_have;
+        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
         const u32 fin = c_fin;
         u32 R = c_R;
         {
@@ -1451,57 +1454,79 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // order the kernels take their tiles in (PlaceArgs::perm); a batch in which most reads have no three of the seven within a window
 // of each other (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
-
 constexpr int RETILE_BINS = 64;
-// hist[0..63]: reads per key; hist[64]: reads without three sampled k-mers that agree; hist[65]: 1 = keep the order
+// hist[0..63]: reads per key; hist[64] / hist[66]: sampled reads without a clade / sampled reads; hist[65]: 1 = keep the order
+template <int BITS>
+__device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &spread) {
+    const u32 k = a.db.k, wpr = a.words_per_read;
+    u32 R = a.lens ? a.lens[r] : a.fixed_len;
+    const u32 cap_syms = (wpr * 32u) / BITS;
+    R = R < cap_syms ? R : cap_syms;
+    const u32 fin = a.flags_in ? a.flags_in[r] : 0u;
+    const bool plain = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG)) == 0 && R >= k;
+    u32 key = 0;
+    spread = 0;
+    if (plain) {
+        const u32 Q = R - k + 1;
+        const u32 *rec = a.packed + r * wpr;
+        constexpr int NS = 7;
+        u32 w[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const u32 p_ = (u32)(((u64)(Q - 1) * (u32)i) / (NS - 1));
+            w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, p_, k), k)] & 63u;
+        }
+        // the window most of the seven agree on (to within one): k-mers that also occur elsewhere in the reference (their rows are
+        // filed under another clade), or that every clade shares, do not move the key while a few of the seven are at home
+        u32 best = 0, best_n = 0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            u32 n_ = 0;
+#pragma unroll
+            for (int j = 0; j < NS; j++) n_ += (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u ? 1u : 0u;
+            best = n_ > best_n ? w[i] : best;
+            best_n = max(best_n, n_);
+        }
+        key = best;
+        spread = best_n < 3u ? 1u : 0u;  // no three of them within a window of each other: a read without a clade (uniform reads)
+    }
+    return key;
+}
+// first a look at one read in sixteen: hist[66] = reads looked at, hist[64] = those without a clade; a batch of such reads keeps its
+// order and the full pass below ends at its first instruction (a uniform batch pays a sixteenth of the keys)
+template <int BITS>
+__global__ void __launch_bounds__(256) retile_sample_kernel(PlaceArgs a, u32 *hist) {
+    const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    u32 spread = 0;
+    const bool on = r < a.n_reads;
+    if (on) (void)retile_read_key<BITS>(a, r, spread);
+    const u64 sp = __ballot(on && spread != 0u), al = __ballot(on);
+    if ((threadIdx.x & 63u) == 0) {
+        if (sp) atomicAdd(&hist[RETILE_BINS], (u32)__builtin_popcountll(sp));
+        if (al) atomicAdd(&hist[RETILE_BINS + 2], (u32)__builtin_popcountll(al));
+    }
+}
+__global__ void retile_decide_kernel(u32 *hist) {
+    if (threadIdx.x == 0) hist[RETILE_BINS + 1] = (hist[RETILE_BINS] * 2u > hist[RETILE_BINS + 2]) ? 1u : 0u;
+}
 template <int BITS>
 __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned char *keys, u32 *hist) {
-    __shared__ u32 h[RETILE_BINS + 1];
-    if (threadIdx.x <= RETILE_BINS) h[threadIdx.x] = 0;
+    if (hist[RETILE_BINS + 1]) return;  // the batch keeps its order
+    __shared__ u32 h[RETILE_BINS];
+    if (threadIdx.x < RETILE_BINS) h[threadIdx.x] = 0;
     __syncthreads();
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < a.n_reads) {
-        const u32 k = a.db.k, wpr = a.words_per_read;
-        u32 R = a.lens ? a.lens[r] : a.fixed_len;
-        const u32 cap_syms = (wpr * 32u) / BITS;
-        R = R < cap_syms ? R : cap_syms;
-        const u32 fin = a.flags_in ? a.flags_in[r] : 0u;
-        const bool plain = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG)) == 0 && R >= k;
-        u32 key = 0, spread = 0;
-        if (plain) {
-            const u32 Q = R - k + 1;
-            const u32 *rec = a.packed + r * wpr;
-            constexpr int NS = 7;
-            u32 w[NS];
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                const u32 p_ = (u32)(((u64)(Q - 1) * (u32)i) / (NS - 1));
-                w[i] = a.db.winspec[(u32)dense_index<BITS>(extract_code<BITS>(rec, wpr, p_, k), k)] & 63u;
-            }
-            // the window most of the seven agree on (to within one): k-mers that also occur elsewhere in the reference (their rows are
-            // filed under another clade), or that every clade shares, do not move the key while a few of the seven are at home
-            u32 best = 0, best_n = 0;
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                u32 n_ = 0;
-#pragma unroll
-                for (int j = 0; j < NS; j++) n_ += (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u ? 1u : 0u;
-                best = n_ > best_n ? w[i] : best;
-                best_n = max(best_n, n_);
-            }
-            key = best;
-            spread = best_n < 3u ? 1u : 0u;  // no three of them within a window of each other: a read without a clade (uniform reads)
-        }
+        u32 spread;
+        const u32 key = retile_read_key<BITS>(a, r, spread);
         keys[r] = (unsigned char)key;
         atomicAdd(&h[key], 1u);
-        if (spread) atomicAdd(&h[RETILE_BINS], 1u);
     }
     __syncthreads();
-    if (threadIdx.x <= RETILE_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < RETILE_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
-// one block: start of every key's range (cursor[0..63]), and whether the batch is re-tiled at all
-__global__ void __launch_bounds__(64) retile_scan_kernel(u64 n_reads, u32 *hist, u32 *cursor) {
+// one block: start of every key's range (cursor[0..63])
+__global__ void __launch_bounds__(64) retile_scan_kernel(u32 *hist, u32 *cursor) {
     const u32 t = threadIdx.x;
     u32 v = hist[t], incl = v;
     for (int s = 1; s < 64; s <<= 1) {
@@ -1509,7 +1534,6 @@ __global__ void __launch_bounds__(64) retile_scan_kernel(u64 n_reads, u32 *hist,
         if ((int)t >= s) incl += o;
     }
     cursor[t] = incl - v;
-    if (t == 0) hist[RETILE_BINS + 1] = ((u64)hist[RETILE_BINS] * 2 > n_reads) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) retile_scatter_kernel(u64 n_reads, const unsigned char *keys, const u32 *hist, u32 *cursor, u32 *perm) {
     __shared__ u32 cnt[RETILE_BINS], base[RETILE_BINS];

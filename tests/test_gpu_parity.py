@@ -722,10 +722,10 @@ def test_best_branches_that_are_neighbours(n_branches, K):
             run_case(sdb, odb, seq, off, "direct", lanes, "mean", keepAtMost=K, keepFactor=0.0)
 
 
-@pytest.mark.parametrize("n_branches", [3999, 9001, 20001, 65535])
+@pytest.mark.parametrize("n_branches", [399, 999, 3999, 9001, 20001, 65535])
 def test_tiles_of_reads_that_hit_the_same_windows(n_branches, monkeypatch, dev_lib):
-    """the windowed kernels take their tiles through the order a counting sort by window gives (PlaceArgs::perm; batches of 32 768 reads
-    and more in the product, every batch here): clade-shaped reads -- re-tiled -- mixed with uniform ones, ragged lengths, ambiguity
+    """the 16-lane dense and the windowed kernels take their tiles through the order a counting sort by the reads' place in the tree
+    gives (PlaceArgs::perm; batches of 32 768 reads and more in the product, every batch here): clade-shaped reads -- re-tiled -- mixed with uniform ones, ragged lengths, ambiguity
     codes and unsupported characters (reads the ASCII kernel or nobody places keep their own index too), a batch that is not a
     multiple of four, and a batch of uniform reads alone (the order is kept)"""
     monkeypatch.setenv("RK_RETILE_MIN_READS", "0")
