@@ -83,7 +83,8 @@ struct PlaceArgs {
     u32 n_pass;    // large-tree kernels: branch-range passes per read (1 unless the score vector exceeds one CU's LDS)
     u32 main_cap, work_cap;  // windowed kernels: u32 slots of the per-read item list / of the per-window work (touched-slot) list
     u32 only_marked;         // place_packed16w_kernel as the second launch: only tiles whose first read carries RK_FLAG_INTERNAL_DEFERRED
-    const u32 *perm;         // windowed kernels: tile t holds reads perm[4t .. 4t+3] (reads grouped by the windows they hit); null = in order
+    const u32 *perm;         // tile t holds reads perm[4t .. 4t+3] (reads grouped by their place in the tree); null = in order
+    const u32 *keep_order;   // with perm: *keep_order != 0 = the pre-pass found a batch of reads without a clade and left perm unwritten
 };
 
 // set by place_packed16s_kernel in the flag word of a tile's first read when the tile is left to place_packed16w_kernel, which

@@ -16,6 +16,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <atomic>
 #include <mutex>
@@ -1265,13 +1266,29 @@ struct TileOrder {
     ~TileOrder() { if (p) (void)hipFreeAsync(p, s); }
     TileOrder(const TileOrder &) = delete;
     TileOrder &operator=(const TileOrder &) = delete;
+    static void keep_pool_memory() {  // (the default pool hands freed memory back at every synchronisation: 0.2 ms of allocation per launch)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        static std::mutex mu;
+        static std::set<int> done;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done.insert(dev).second) return;
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t thr = 1ull << 30;  // keep up to 1 GB of freed scratch around
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+        }
+        (void)hipGetLastError();
+    }
     int prepare(const rk_db *db, PlaceArgs &a) {
         a.perm = nullptr;
+        a.keep_order = nullptr;
         if (!db->view.winspec) return RK_OK;  // (images without a position byte per k-mer: hashed tables, the large-tree image)
         uint64_t retile_min = 32768;
         if (const char *e = rk_knob("RK_RETILE_MIN_READS")) retile_min = (uint64_t)atoll(e);  // developer / test knob (0 = always)
         if (a.n_reads < retile_min || a.n_reads >= (1ull << 32) || rk_knob("RK_NO_RETILE")) return RK_OK;
         const size_t perm_off = 1024, keys_off = perm_off + (((size_t)a.n_reads * 4 + 255) & ~(size_t)255), total = keys_off + a.n_reads;
+        keep_pool_memory();
         if (hipMallocAsync(&p, total, s) != hipSuccess || !p) {
             (void)hipGetLastError();
             p = nullptr;
@@ -1281,8 +1298,8 @@ struct TileOrder {
         uint32_t *hist = (uint32_t *)base, *cursor = hist + 128, *perm = (uint32_t *)(base + perm_off);
         unsigned char *keys = base + keys_off;
         HIP_TRY(hipMemsetAsync(base, 0, perm_off, s));
-        const unsigned nblk = (unsigned)((a.n_reads + 255) / 256);
-        const unsigned sblk = (unsigned)((a.n_reads / 16 + 255) / 256 + 1);
+        const unsigned nblk = (unsigned)std::min<uint64_t>((a.n_reads + 255) / 256, 2048);  // (grid-stride: a batch that keeps its order ends 2 048 blocks, not a million threads)
+        const unsigned sblk = (unsigned)((a.n_reads / 64 + 255) / 256 + 1);
         if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_sample_kernel<2>, dim3(sblk), dim3(256), 0, s, a, hist);
         else hipLaunchKernelGGL(retile_sample_kernel<5>, dim3(sblk), dim3(256), 0, s, a, hist);
         hipLaunchKernelGGL(retile_decide_kernel, dim3(1), dim3(64), 0, s, hist);
@@ -1292,6 +1309,7 @@ struct TileOrder {
         hipLaunchKernelGGL(retile_scatter_kernel, dim3(nblk), dim3(256), 0, s, a.n_reads, (const unsigned char *)keys, (const uint32_t *)hist, cursor, perm);
         HIP_TRY(hipGetLastError());
         a.perm = perm;
+        a.keep_order = hist + 65;  // (RETILE_BINS + 1)
         return RK_OK;
     }
 };

@@ -85,7 +85,8 @@ __device__ __forceinline__ double shfl_f64(double v, int src, int width) {
     return __longlong_as_double((long long)shfl64((u64)__double_as_longlong(v), src, width));
 }
 // the read a tile's slot stands for: PlaceArgs::perm when the batch's reads were grouped by their place in the tree (retile_* below)
-__device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot) { return a.perm ? (u64)a.perm[slot] : slot; }
+__device__ __forceinline__ bool tile_order_given(const PlaceArgs &a) { return a.perm != nullptr && *a.keep_order == 0u; }  // (once per wave)
+__device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot, bool given) { return given ? (u64)a.perm[slot] : slot; }
 // LDS data exchanged between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be stopped from reordering / caching.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -898,6 +899,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     constexpr int LOG2G = G == 8 ? 3 : (G == 16 ? 4 : (G == 32 ? 5 : 6));
     typedef typename ItemT<WIDE>::type item_t;
     extern __shared__ u32 lds[];
+    const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
     const u32 waves_per_block = blockDim.x >> 6;
@@ -930,7 +932,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
 #endif
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         const bool have = tile * NG + gi < a.n_reads;
-        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
+        const u64 r = have ? tile_read(a, tile * NG + gi, perm_given) : 0ull;
         u32 R = 0, fin = 0;
         if (have) {
             R = a.lens ? a.lens[r] : a.fixed_len;
@@ -950,7 +952,7 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
         u32 warm = 0;
         {
             const u64 sn = (tile + wave_count) * NG + gi;
-            if (sn < a.n_reads) warm = a.packed[tile_read(a, sn) * a.words_per_read + (li < a.words_per_read ? li : 0u)];
+            if (sn < a.n_reads) warm = a.packed[tile_read(a, sn, perm_given) * a.words_per_read + (li < a.words_per_read ? li : 0u)];
         }
 
         u32 pos = 0;
@@ -1207,6 +1209,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
     constexpr int G = 16, NG = 4;
     static_assert(TM != TM_HASH, "direct tables only");
     extern __shared__ u32 lds[];
+    const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
     const u32 waves_per_block = blockDim.x >> 6;
@@ -1236,7 +1239,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
     auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
         const u64 slot = tile * NG + gi;
         have = tile < n_tiles && slot < a.n_reads;
-        const u64 r = have ? tile_read(a, slot) : 0ull;
+        const u64 r = have ? tile_read(a, slot, perm_given) : 0ull;
         recw = 0; R = 0; fin = 0;
         if (have) {
             if (li < wpr) recw = a.packed[r * wpr + li];
@@ -1284,7 +1287,7 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         const bool have = c_have;
-        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
+        const u64 r = have ? tile_read(a, tile * NG + gi, perm_given) : 0ull;
         const u32 fin = c_fin;
         u32 R = c_R;
         {
@@ -1483,7 +1486,8 @@ __device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &s
         for (int i = 0; i < NS; i++) {
             u32 n_ = 0;
 #pragma unroll
-            for (int j = 0; j < NS; j++) n_ += (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u ? 1u : 0u;
+            for (int j = 0; j < NS; j++) n_ += (w[j] != 0u && (w[i] > w[j] ? w[i] - w[j] : w[j] - w[i]) <= 1u) ? 1u : 0u;
+            n_ = w[i] != 0u ? n_ : 0u;  // (0 = no row for this k-mer -- or the first range of the tree, which is not told apart: no vote)
             best = n_ > best_n ? w[i] : best;
             best_n = max(best_n, n_);
         }
@@ -1492,11 +1496,11 @@ __device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &s
     }
     return key;
 }
-// first a look at one read in sixteen: hist[66] = reads looked at, hist[64] = those without a clade; a batch of such reads keeps its
-// order and the full pass below ends at its first instruction (a uniform batch pays a sixteenth of the keys)
+// first a look at one read in sixty-four: hist[66] = reads looked at, hist[64] = those without a clade; a batch of such reads keeps
+// its order and the full pass below ends at its first instruction (a uniform batch pays a sixty-fourth of the keys)
 template <int BITS>
 __global__ void __launch_bounds__(256) retile_sample_kernel(PlaceArgs a, u32 *hist) {
-    const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 64u;
     u32 spread = 0;
     const bool on = r < a.n_reads;
     if (on) (void)retile_read_key<BITS>(a, r, spread);
@@ -1515,8 +1519,7 @@ __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned c
     __shared__ u32 h[RETILE_BINS];
     if (threadIdx.x < RETILE_BINS) h[threadIdx.x] = 0;
     __syncthreads();
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < a.n_reads) {
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (u64)gridDim.x * blockDim.x) {
         u32 spread;
         const u32 key = retile_read_key<BITS>(a, r, spread);
         keys[r] = (unsigned char)key;
@@ -1537,28 +1540,29 @@ __global__ void __launch_bounds__(64) retile_scan_kernel(u32 *hist, u32 *cursor)
 }
 __global__ void __launch_bounds__(256) retile_scatter_kernel(u64 n_reads, const unsigned char *keys, const u32 *hist, u32 *cursor, u32 *perm) {
     __shared__ u32 cnt[RETILE_BINS], base[RETILE_BINS];
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (hist[RETILE_BINS + 1]) {  // (block-uniform) the batch keeps its order
-        if (r < n_reads) perm[r] = (u32)r;
-        return;
+    if (hist[RETILE_BINS + 1]) return;  // the batch keeps its order (PlaceArgs::keep_order points here: perm is not read)
+    for (u64 r0 = (u64)blockIdx.x * blockDim.x; r0 < n_reads; r0 += (u64)gridDim.x * blockDim.x) {  // (block-uniform trip count)
+        const u64 r = r0 + threadIdx.x;
+        if (threadIdx.x < RETILE_BINS) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        u32 key = 0, rank = 0;
+        if (r < n_reads) {
+            key = keys[r];
+            rank = atomicAdd(&cnt[key], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < RETILE_BINS && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);
+        __syncthreads();
+        if (r < n_reads) perm[base[key] + rank] = (u32)r;
+        __syncthreads();
     }
-    if (threadIdx.x < RETILE_BINS) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    u32 key = 0, rank = 0;
-    if (r < n_reads) {
-        key = keys[r];
-        rank = atomicAdd(&cnt[key], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < RETILE_BINS && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);
-    __syncthreads();
-    if (r < n_reads) perm[base[key] + rank] = (u32)r;
 }
 
 template <int BITS, int U, int PU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16w_kernel(PlaceArgs a) {  // (amino acids: 286 registers left to itself = one wave per SIMD; DNA: 219, and slower when asked for two)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT;
     extern __shared__ u32 lds[];
+    const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
     const u32 waves_per_block = blockDim.x >> 6;
@@ -1594,7 +1598,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
         const u64 slot = tile * NG + gi;
         have = tile < n_tiles && slot < a.n_reads;
-        const u64 r = have ? tile_read(a, slot) : 0ull;
+        const u64 r = have ? tile_read(a, slot, perm_given) : 0ull;
         recw = 0; R = 0; fin = 0;
         if (have) {
             if (li < wpr) recw = a.packed[r * wpr + li];
@@ -1657,14 +1661,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         if (a.only_marked) {  // second launch behind place_packed16s_kernel: only the tiles it handed over (their first read's flag word)
-            const u32 mark = a.o_flags[tile_read(a, tile * NG)] & RK_FLAG_INTERNAL_DEFERRED;
+            const u32 mark = a.o_flags[tile_read(a, tile * NG, perm_given)] & RK_FLAG_INTERNAL_DEFERRED;
             if (!__builtin_amdgcn_readfirstlane((int)mark)) {
                 load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
                 continue;
             }
         }
         const bool have = c_have;
-        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
+        const u64 r = have ? tile_read(a, tile * NG + gi, perm_given) : 0ull;
         c_rec = a.packed + r * wpr;
         const u32 fin = c_fin;
         u32 R = c_R;
@@ -1953,6 +1957,7 @@ template <int BITS, int U, int PU, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16s_kernel(PlaceArgs a) {  // (amino acids: 264 registers left to itself, one wave per SIMD)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2, TURNS = 8;
     extern __shared__ u32 lds[];
+    const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
     const u32 waves_per_block = blockDim.x >> 6;
@@ -1984,7 +1989,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     auto load_tile = [&](u64 tile, u32 &recw, u32 &R, u32 &fin, bool &have) {
         const u64 slot = tile * NG + gi;
         have = tile < n_tiles && slot < a.n_reads;
-        const u64 r = have ? tile_read(a, slot) : 0ull;
+        const u64 r = have ? tile_read(a, slot, perm_given) : 0ull;
         recw = 0; R = 0; fin = 0;
         if (have) {
             if (li < wpr) recw = a.packed[r * wpr + li];
@@ -2006,7 +2011,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
         const bool have = c_have;
-        const u64 r = have ? tile_read(a, tile * NG + gi) : 0ull;
+        const u64 r = have ? tile_read(a, tile * NG + gi, perm_given) : 0ull;
         const u32 fin = c_fin, recw = c_recw;
         u32 R = c_R;
         {
@@ -2092,7 +2097,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #ifdef RK_STAMPS
             st_[10] += 1;
 #endif
-            if (lane == 0) a.o_flags[tile_read(a, tile * NG)] = RK_FLAG_INTERNAL_DEFERRED;
+            if (lane == 0) a.o_flags[tile_read(a, tile * NG, perm_given)] = RK_FLAG_INTERNAL_DEFERRED;
             wave_lds_fence();
             continue;
         }
@@ -2400,7 +2405,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             }
         }
         if (__any(cand_over)) {  // (wave-uniform) rare twice over: the tile is left to place_packed16w_kernel; S is in its reset state
-            if (lane == 0) a.o_flags[tile_read(a, tile * NG)] = RK_FLAG_INTERNAL_DEFERRED;
+            if (lane == 0) a.o_flags[tile_read(a, tile * NG, perm_given)] = RK_FLAG_INTERNAL_DEFERRED;
 #ifdef RK_STAMPS
             st_[10] += 1;
 #endif
