@@ -199,3 +199,37 @@ def test_long_kmers_and_long_records_at_scale(case):
             compare_with_oracle(part, odb.place(s2, o2), odb, s2, o2)
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("n_branches", [999, 20001])
+def test_clade_shaped_batch_at_the_size_the_tile_order_starts_from(n_branches):
+    """80 000 clade-shaped reads (rappas_amd.synth.make_clade_db: reads cut from a genome whose k-mers make up the database) mixed with
+    uniform ones: from 32 768 reads on the kernels take their tiles in the order of a counting sort by the reads' place in the tree
+    (PlaceArgs::perm).  A read's result does not depend on what shares its batch: the whole batch, its two halves -- another order --
+    and the oracle on a slice have to agree, read for read."""
+    import torch
+    sdb, genome = synth.make_clade_db(k=10, n_branches=n_branches, genome_len=200_000)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    pp = ra.PlacementProcess(db)
+    n = 80_000
+    s1, o1 = synth.make_clade_reads(genome, 60_000, R, seed=3)
+    s2, o2 = synth.make_reads(4, 20_000, R, seed=4)
+    seq = np.concatenate([s1, s2]).reshape(n, R)
+    order = np.random.default_rng(n_branches).permutation(n)
+    seq = np.ascontiguousarray(seq[order]).reshape(-1)
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(R))
+    packed, _, _ = pp.pack_reads_host(seq, off)
+    pk = torch.from_numpy(packed.view(np.int32)).cuda()
+    whole = pp.place_packed(pk, fixed_len=R)
+    halves = [pp.place_packed(pk[i:i + n // 2].contiguous(), fixed_len=R) for i in (0, n // 2)]
+    torch.cuda.synchronize()
+    for name in ("n_rows", "branch", "score", "lwr", "flags"):
+        both = torch.cat([h[name] for h in halves])
+        assert torch.equal(whole[name], both), name
+    nv = 400
+    got = ra.Placements(whole["n_rows"][:nv].cpu().numpy(), whole["branch"][:nv].cpu().numpy().view(np.uint16), whole["score"][:nv].cpu().numpy(),
+                        whole["lwr"][:nv].cpu().numpy(), whole["flags"][:nv].cpu().numpy().view(np.uint32), {})
+    odb = O.OracleDB.from_synth(sdb)
+    st = compare_with_oracle(got, odb.place(seq[:nv * R], off[:nv + 1]), odb, seq[:nv * R], off[:nv + 1])
+    assert st["placed"] > 350
+    db.close()
