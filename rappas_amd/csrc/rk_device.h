@@ -82,14 +82,13 @@ struct PlaceArgs {
     u32 list_cap;  // u64 slots of the per-read hit list in LDS
     u32 n_pass;    // large-tree kernels: branch-range passes per read (1 unless the score vector exceeds one CU's LDS)
     u32 main_cap, work_cap;  // windowed kernels: u32 slots of the per-read item list / of the per-window work (touched-slot) list
-    u32 only_marked;         // place_packed16w_kernel as the second launch: only tiles whose first read carries RK_FLAG_INTERNAL_DEFERRED
+    u32 only_marked;         // place_packed16w_kernel as the second launch: only the tiles marked in tile_marks
+    unsigned char *tile_marks;  // [ceil(n_reads / 4)] scratch of the launch (zeroed before the first kernel): tile t -- the reads at slots 4t .. 4t+3 of the
+                                // batch's order -- is left to place_packed16w_kernel by the kernel launched ahead of it (never the caller's flag array:
+                                // d_flags_in may be the same buffer as the output flags)
     const u32 *perm;         // tile t holds reads perm[4t .. 4t+3] (reads grouped by their place in the tree); null = in order
     const u32 *keep_order;   // with perm: *keep_order != 0 = the pre-pass found a batch of reads without a clade and left perm unwritten
 };
-
-// set by place_packed16s_kernel in the flag word of a tile's first read when the tile is left to place_packed16w_kernel, which
-// overwrites it with the read's real flags; never visible to a caller
-constexpr u32 RK_FLAG_INTERNAL_DEFERRED = 0x80000000u;
 
 __device__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;

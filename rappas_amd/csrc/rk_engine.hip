@@ -51,9 +51,15 @@ using namespace rk;
 #endif
 #ifndef RK_WRING
 #define RK_WRING RK_RING  // the same for the windowed kernel
+#endif
 #ifndef RK_RING64
 #define RK_RING64 8  // ... and for the 64-lane geometry (one wave per read: large trees with long rows, one or two waves per SIMD)
 #endif
+#ifndef RK_HRING
+#define RK_HRING 2  // ... and for the hash-accumulator kernel (place_hash64_kernel: steps of RK_HNPL entries per lane = 4 * RK_HNPL row units)
+#endif
+#ifndef RK_HNPL
+#define RK_HNPL 4
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -468,6 +474,13 @@ struct rk_db {
     std::mutex host_mutex;             // rk_place_batch (host path) owns the workspaces below
     rk_workspace ws[4];                // device buffers + stream per in-flight chunk (grow-only)
     std::string kernel_name;
+    // Scratch of the launches themselves (the tile order's keys / histogram / permutation, the marks of the tiles one kernel hands to
+    // the next): one grow-only block per stream a caller has launched on, owned by the handle -- the library allocates from no pool
+    // the hosting process shares and changes no attribute of one (launch_scratch)
+    struct LaunchScratch { hipStream_t s; void *p; size_t cap; uint64_t used; };
+    mutable std::mutex scratch_mu;
+    mutable std::vector<LaunchScratch> scratch;
+    mutable uint64_t scratch_clock = 0;
 };
 
 static uint64_t host_mix64(uint64_t x) {
@@ -496,6 +509,8 @@ extern "C" void rk_db_destroy(rk_db *db) {
     if (db->d_winspec) (void)hipFree(db->d_winspec);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     for (rk_workspace &w : db->ws) w.release();
+    for (rk_db::LaunchScratch &b : db->scratch)
+        if (b.p) (void)hipFree(b.p);
     if (prev >= 0) (void)hipSetDevice(prev);
     delete db;
 }
@@ -1256,48 +1271,83 @@ static bool use_windowed(const rk_db *db, uint32_t keep_at_most, uint32_t words_
     return !off && db->windowed && db->lanes_per_read == 0 && keep_at_most <= 16 && fits;
 }
 
-// ---- tiles of reads that sit in the same part of the tree (rk_kernels.hip: retile_*): keys, counting sort, the order the kernels take
-//      their tiles in (PlaceArgs::perm).  Scratch is the stream's own (allocated and freed in stream order); without it, or below
-//      32 768 reads (the pre-pass's three launches cost more than they can win), the batch keeps its order ----
-struct TileOrder {
-    void *p = nullptr;
-    hipStream_t s;
-    explicit TileOrder(hipStream_t st) : s(st) {}
-    ~TileOrder() { if (p) (void)hipFreeAsync(p, s); }
-    TileOrder(const TileOrder &) = delete;
-    TileOrder &operator=(const TileOrder &) = delete;
-    static void keep_pool_memory() {  // (the default pool hands freed memory back at every synchronisation: 0.2 ms of allocation per launch)
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return;
-        static std::mutex mu;
-        static std::set<int> done;
-        std::lock_guard<std::mutex> lock(mu);
-        if (!done.insert(dev).second) return;
-        hipMemPool_t pool = nullptr;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-            uint64_t thr = 1ull << 30;  // keep up to 1 GB of freed scratch around
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+// ---- scratch of a launch: owned by the handle, one grow-only block per stream a caller launches on.  Nothing is taken from (and no
+//      attribute is set on) the device's default memory pool, which the hosting process -- a JVM, PyTorch -- shares.  Returns nullptr
+//      when the block would have to grow and cannot right now (the stream is being captured into a graph, the device is out of
+//      memory): the callers then do without it (batch order kept, place_packed16w_kernel alone).  Calls on ONE stream must not
+//      overlap in time (include/rappas_place.h): growing the block waits for the stream's work and frees the old one ----
+static void *launch_scratch(const rk_db *db, hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lock(db->scratch_mu);
+    rk_db::LaunchScratch *b = nullptr;
+    for (auto &x : db->scratch)
+        if (x.s == s) { b = &x; break; }
+    if (!b) {
+        if (db->scratch.size() >= 16) {  // a caller that makes a stream per call: the least recently used block goes (its stream may be gone, so the whole device is waited for)
+            auto lru = std::min_element(db->scratch.begin(), db->scratch.end(), [](const rk_db::LaunchScratch &x, const rk_db::LaunchScratch &y) { return x.used < y.used; });
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            if (lru->p) (void)hipFree(lru->p);
+            db->scratch.erase(lru);
         }
-        (void)hipGetLastError();
+        db->scratch.push_back({s, nullptr, 0, 0});
+        b = &db->scratch.back();
     }
-    int prepare(const rk_db *db, PlaceArgs &a) {
+    b->used = ++db->scratch_clock;
+    if (b->cap < bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (b->p) {
+            if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            (void)hipFree(b->p);
+            b->p = nullptr;
+            b->cap = 0;
+        }
+        const size_t want = ((bytes + bytes / 4) + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (hipMalloc(&b->p, want) != hipSuccess || !b->p) {
+            (void)hipGetLastError();
+            b->p = nullptr;
+            return nullptr;
+        }
+        b->cap = want;
+    }
+    return b->p;
+}
+
+// ---- tiles of reads that sit in the same part of the tree (rk_kernels.hip: retile_*): keys, counting sort, the order the kernels take
+//      their tiles in (PlaceArgs::perm); and the marks of the tiles a first kernel hands to place_packed16w_kernel
+//      (PlaceArgs::tile_marks, one byte per tile of four reads).  Without scratch, or below 32 768 reads (the pre-pass's launches
+//      cost more than they can win), the batch keeps its order ----
+struct TileOrder {
+    unsigned char *marks = nullptr;  // zeroed by prepare() when asked for
+    int prepare(const rk_db *db, PlaceArgs &a, hipStream_t s, bool want_marks) {
         a.perm = nullptr;
         a.keep_order = nullptr;
-        if (!db->view.winspec) return RK_OK;  // (images without a position byte per k-mer: hashed tables, the large-tree image)
+        a.tile_marks = nullptr;
         uint64_t retile_min = 32768;
         if (const char *e = rk_knob("RK_RETILE_MIN_READS")) retile_min = (uint64_t)atoll(e);  // developer / test knob (0 = always)
-        if (a.n_reads < retile_min || a.n_reads >= (1ull << 32) || rk_knob("RK_NO_RETILE")) return RK_OK;
-        const size_t perm_off = 1024, keys_off = perm_off + (((size_t)a.n_reads * 4 + 255) & ~(size_t)255), total = keys_off + a.n_reads;
-        keep_pool_memory();
-        if (hipMallocAsync(&p, total, s) != hipSuccess || !p) {
-            (void)hipGetLastError();
-            p = nullptr;
-            return RK_OK;
+        // (images without a position byte per k-mer -- hashed tables, the large-tree image -- keep their order)
+        const bool retile = db->view.winspec && a.n_reads >= retile_min && a.n_reads < (1ull << 32) && !rk_knob("RK_NO_RETILE");
+        if (!retile && !want_marks) return RK_OK;
+        const size_t n_tiles = (size_t)((a.n_reads + 3) / 4);
+        const size_t marks_off = 1024, perm_off = marks_off + (want_marks ? ((n_tiles + 255) & ~(size_t)255) : 0);
+        const size_t keys_off = perm_off + (retile ? (((size_t)a.n_reads * 4 + 255) & ~(size_t)255) : 0), total = keys_off + (retile ? a.n_reads : 0);
+        unsigned char *base = (unsigned char *)launch_scratch(db, s, total);
+        if (!base) return RK_OK;
+        if (want_marks) {
+            marks = base + marks_off;
+            HIP_TRY(hipMemsetAsync(marks, 0, n_tiles, s));
+            a.tile_marks = marks;
         }
-        unsigned char *base = (unsigned char *)p;
+        if (!retile) return RK_OK;
         uint32_t *hist = (uint32_t *)base, *cursor = hist + 128, *perm = (uint32_t *)(base + perm_off);
         unsigned char *keys = base + keys_off;
-        HIP_TRY(hipMemsetAsync(base, 0, perm_off, s));
+        HIP_TRY(hipMemsetAsync(base, 0, marks_off, s));
         const unsigned nblk = (unsigned)std::min<uint64_t>((a.n_reads + 255) / 256, 2048);  // (grid-stride: a batch that keeps its order ends 2 048 blocks, not a million threads)
         const unsigned sblk = (unsigned)((a.n_reads / 64 + 255) / 256 + 1);
         if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_sample_kernel<2>, dim3(sblk), dim3(256), 0, s, a, hist);
@@ -1314,6 +1364,34 @@ struct TileOrder {
     }
 };
 
+// place_hash64_kernel's geometry: NS = 2 048 slots (16 KB) + a word per lane + a list of 320 items = 17 920 B per wave, nine waves per CU
+#ifndef RK_HASH_LOGS
+#define RK_HASH_LOGS 11
+#endif
+constexpr uint32_t RK_HASH_LOG_SLOTS = RK_HASH_LOGS, RK_HASH_MAIN_CAP = 320;
+#ifndef RK_HASH_KEY_SLACK
+#define RK_HASH_KEY_SLACK 192u  // slots kept free: a table takes NS - this many keys before a step (profiles/r04_hash_knobs.txt)
+#endif
+// From this many branches on place_hash64_kernel is ahead of place_packed16s_kernel, whose cost grows with the windows a tree is cut
+// into (profiles/r04_hash_crossover.txt; C2-like rows, Mreads/s hash / sorted-stream: 19 999 branches 88 / 102, 39 999: 84 / 68,
+// 65 535: 80 / 34; clade-shaped reads 79 / 121 at 19 999, 79 / 45 at 65 535)
+#ifndef RK_HASH_MIN_BRANCHES
+#define RK_HASH_MIN_BRANCHES 28000u
+#endif
+static bool hash_tree(const rk_db *db) {  // images whose tiles go to place_hash64_kernel first
+    if (rk_knob("RK_NO_HASH") || rk_knob("RK_NO_WSTREAM") || db->info.rows_bytes >= ROWS_FIT32_LIMIT) return false;
+    if (rk_knob("RK_HASH_ALWAYS")) return true;
+    return db->wp.stream && db->info.n_branches > RK_HASH_MIN_BRANCHES;
+}
+static uint32_t hash_key_limit() {
+    uint32_t slack = RK_HASH_KEY_SLACK;
+    if (const char *e = rk_knob("RK_HASH_KEY_SLACK")) slack = (uint32_t)atoi(e);  // developer knob
+    const uint32_t ns = 1u << RK_HASH_LOG_SLOTS;
+    if (slack < 64u * RK_HNPL + 16u) slack = 64u * RK_HNPL + 16u;  // a step adds up to 64 keys per entry of a lane: the table is never full
+    if (slack > ns - 64u) slack = ns - 64u;
+    return ns - slack;
+}
+
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     WindowPlan wp = db->wp;
     const uint64_t n_tiles = (a.n_reads + 3) / 4;
@@ -1325,10 +1403,33 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     // (reads of one known length whose k-mers do not fit its single probe batch would all be handed over: not launched for those)
     const uint32_t probe_cap = (db->info.bits_per_symbol == 5 ? 7u : 9u) * 16u;
     const bool one_batch = a.lens != nullptr || a.fixed_len < db->info.k || a.fixed_len - db->info.k + 1 <= probe_cap;
-    const bool sorted_first = a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
-    TileOrder order(stream);
-    if (int rc = order.prepare(db, a)) return rc;
-    if (sorted_first) {
+    // place_hash64_kernel first: images of short rows (the rule place_packed16s_kernel had), reads whose distinct branches -- at most
+    // their entries, ~9.3 a unit with C2-like rows -- fit the table (profiles/r04_lsize_hist.txt)
+    const bool hash_first = !no_stream && hash_tree(db) && (est_units * 9.3 <= 0.8 * hash_key_limit() || rk_knob("RK_HASH_ALWAYS"));
+    const bool sorted_first = !hash_first && a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
+    TileOrder order;
+    if (int rc = order.prepare(db, a, stream, hash_first || sorted_first)) return rc;
+    const bool first_ok = a.tile_marks != nullptr;  // (no scratch to be had for the marks: place_packed16w_kernel alone)
+    if (hash_first && first_ok) {
+        PlaceArgs b = a;
+        b.s_stride = 1u << RK_HASH_LOG_SLOTS; b.main_cap = RK_HASH_MAIN_CAP; b.work_cap = hash_key_limit(); b.list_cap = 0; b.only_marked = 0;
+        const size_t lds_wave = (size_t)(2 * b.s_stride + 64 + b.main_cap) * 4;
+        auto launch = [&](auto kern) -> int {
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+            uint64_t per_cu = 0;
+            uint64_t want = db->lds_per_cu / lds_wave;
+            if (const char *e = rk_knob("RK_HASH_WAVES")) want = std::min<uint64_t>(want, (uint64_t)atoi(e));  // developer knob
+            if (int rc = resident_blocks(kern, 64, lds_wave, want, per_cu)) return rc;
+            uint64_t blocks = (uint64_t)db->cu_count * per_cu;
+            if (blocks > n_tiles) blocks = n_tiles;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, b);
+            return RK_OK;
+        };
+        int rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS>);
+        if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+    }
+    if (sorted_first && first_ok) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
         //      its window segments ----
@@ -1376,7 +1477,7 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         HIP_TRY(hipGetLastError());
     }
     // ---- place_packed16w_kernel: every tile (records of more than 16 words), or the tiles the first kernel handed over ----
-    a.only_marked = sorted_first ? 1u : 0u;
+    a.only_marked = ((hash_first || sorted_first) && first_ok) ? 1u : 0u;
     // 88 words = the 44 keys the exact select of a window needs as scratch for keep_at_most <= 8 (K + 16 candidates + 16 winners); 96 beyond
     const uint32_t work_min = a.keep_at_most > 8 ? 96u : 88u;
     if (wp.work_cap < work_min) {
@@ -1409,8 +1510,8 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
 static int launch_place(const rk_db *db, const Geometry &g, const PlaceArgs &a_in, hipStream_t s) {
     // (reads of one clade read the same rows: taken together they find them in the L2 -- scripts/clade_sorted_probe.py)
     PlaceArgs a = a_in;
-    TileOrder order(s);
-    if (int rc = order.prepare(db, a)) return rc;
+    TileOrder order;
+    if (int rc = order.prepare(db, a, s, false)) return rc;
     switch (g.G) {
     case 8: return launch_b<8>(db, g, a, s);
     case 16: return launch_b<16>(db, g, a, s);
@@ -1584,7 +1685,10 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
-        if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
+        if (hash_tree(db) && (rk_knob("RK_HASH_ALWAYS") || 141.0 * db->wp.units_per_code * 9.3 <= 0.8 * hash_key_limit()))
+            snprintf(buf, sizeof(buf), "place_hash64_kernel<BITS=%u,U=%d,NPL=%d,PU=%d,LOGS=%u> %u slots, <= %u keys a read (+ place_packed16w_kernel for the tiles it hands over; windows=%u x %u branches)",
+                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, RK_HASH_LOG_SLOTS, 1u << RK_HASH_LOG_SLOTS, hash_key_limit(), db->wp.n_win, db->wp.W);
+        else if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
             snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
                      db->info.bits_per_symbol, db->info.bits_per_symbol == 5 ? 7 : 9, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
         else

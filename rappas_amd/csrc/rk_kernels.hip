@@ -635,7 +635,34 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, 
     return num;
 }
 
-// group-wide maximum of a 32-bit value.  G == 16: a group is one DPP row, four rotate-and-max steps, no LDS traffic.
+// Conditions as wave masks (one bit per lane, in an SGPR pair) and selects driven by them: for code whose conditions feed both selects
+// and wave-wide decisions (place_hash64_kernel).  All 64 lanes must be active where these are used.
+__device__ __forceinline__ u64 mask_eq0(u32 v) {
+    u64 m;
+    asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(v));
+    return m;
+}
+__device__ __forceinline__ u64 mask_eq_lo16(u32 a, u32 b) {  // the low 16 bits of a and b are equal
+    u64 m;
+    asm("v_cmp_eq_u16_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ u32 mask_select(u32 if_clear, u32 if_set, u64 m) {
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {  // wave-uniform maximum: four DPP row steps, then the four rows' results through SGPRs
+    v = max(v, row_ror32<8>(v));
+    v = max(v, row_ror32<4>(v));
+    v = max(v, row_ror32<2>(v));
+    v = max(v, row_ror32<1>(v));
+    const u32 m0 = (u32)__builtin_amdgcn_readlane((int)v, 0), m1 = (u32)__builtin_amdgcn_readlane((int)v, 16);
+    const u32 m2 = (u32)__builtin_amdgcn_readlane((int)v, 32), m3 = (u32)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(m0, m1), max(m2, m3));
+}
+
+// group-wide maximum of a 32-bit value.  G == 16: a group is one DPP row, four rotate-and-max steps, no LDS traffic; G == 64: the same per row, then the four rows through SGPRs.
 template <int G>
 __device__ __forceinline__ u32 group_max_u32(u32 v) {
     if (G == 16) {
@@ -643,6 +670,8 @@ __device__ __forceinline__ u32 group_max_u32(u32 v) {
         v = max(v, row_ror32<4>(v));
         v = max(v, row_ror32<2>(v));
         v = max(v, row_ror32<1>(v));
+    } else if (G == 64) {
+        v = wave_max_u32(v);
     } else {
 #pragma unroll
         for (int s = 1; s < G; s <<= 1) v = max(v, (u32)__shfl_xor((int)v, s, G));
@@ -1660,8 +1689,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     load_tile(wave_global, c_recw, c_R, c_fin, c_have);
 
     for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
-        if (a.only_marked) {  // second launch behind place_packed16s_kernel: only the tiles it handed over (their first read's flag word)
-            const u32 mark = a.o_flags[tile_read(a, tile * NG, perm_given)] & RK_FLAG_INTERNAL_DEFERRED;
+        if (a.only_marked) {  // second launch behind place_packed16s_kernel / place_hash64_kernel: only the tiles they handed over
+            const u32 mark = a.tile_marks[tile];
             if (!__builtin_amdgcn_readfirstlane((int)mark)) {
                 load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
                 continue;
@@ -1947,7 +1976,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 //     scores inside a stream are read off the heads at the end (s0 == s1, or dr == s1) and, like a dropped candidate, put the tile in
 //     doubt if they could be among the K best: it then takes the stream a second time and ranks the few entries at or above the K-th
 //     score exactly.
-// Tiles that do not fit are marked (RK_FLAG_INTERNAL_DEFERRED in their first read's flag word) and placed by
+// Tiles that do not fit are marked (PlaceArgs::tile_marks) and placed by
 // place_packed16w_kernel, launched behind this kernel with only_marked set.  Results are identical to the dense kernels'.
 // LDS per read: S[s_stride: 16 scratch words, one per lane, then the window's slots] | list[main_cap] | work[work_cap words: the 64
 // window counters and the 16 idle words of the emit; the bitmap of the stream (16 or 32 words); the 48 keys of the second pass].
@@ -2097,7 +2126,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #ifdef RK_STAMPS
             st_[10] += 1;
 #endif
-            if (lane == 0) a.o_flags[tile_read(a, tile * NG, perm_given)] = RK_FLAG_INTERNAL_DEFERRED;
+            if (lane == 0) a.tile_marks[tile] = 1;
             wave_lds_fence();
             continue;
         }
@@ -2405,7 +2434,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             }
         }
         if (__any(cand_over)) {  // (wave-uniform) rare twice over: the tile is left to place_packed16w_kernel; S is in its reset state
-            if (lane == 0) a.o_flags[tile_read(a, tile * NG, perm_given)] = RK_FLAG_INTERNAL_DEFERRED;
+            if (lane == 0) a.tile_marks[tile] = 1;
 #ifdef RK_STAMPS
             st_[10] += 1;
 #endif
@@ -2420,6 +2449,372 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #ifdef RK_STAMPS
     if (lane == 0 && wave_global < 4096)
         for (int i = 0; i < 16; i++) rk_stamp_buf[wave_global * 16 + i] = st_[i];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// place_hash64_kernel (round 4): large trees with short rows -- a read's scores in a HASH TABLE keyed by branch.
+//
+// A read touches <= ~1 900 distinct branches whatever the tree's size (profiles/r04_lsize_hist.txt: C2-like rows on 7 999 / 19 999 /
+// 65 535 branches, |L| p95 1 449 / 1 529 / 1 571, max 1 889 of 3 000 reads; clade-shaped reads ~500), so the windowed kernels' cost per
+// WINDOW (a sorted emit, a select at every window's end, segments padded to the tile's longest) is replaced by a cost per ENTRY:
+//   * one wave per read; the LDS holds keys[NS] (branch + 1, 0 = empty; a step stamp above bit 17) and vals[NS] (f32 bits, every slot
+//     preset to the read's Q * T: a first touch needs no test) -- 16 KB at NS = 2 048, eight waves per CU at any tree size;
+//   * probe + emit as in the dense kernels: 64 k-mers per round, one item per 128-byte row unit, in k-mer order, no window tags;
+//   * a STEP applies four consecutive units, one per 16-lane row of the wave (64 entries): every lane finds or claims its branch's slot
+//     with an LDS integer compare-and-swap (full rate on gfx950, unlike the LDS float add; triangular probing), then adds
+//     fl(score - T) to vals[slot] by read + add + write.  A row never repeats a branch (CustomHash_v4_FastUtil81.java:78-82) but the
+//     four units of a step may belong to different k-mers: the lanes stamp their slot with the step's number (one returning integer
+//     LDS max on the key word) and, if any lane finds the stamp already there, the step's four units are applied one after the
+//     other -- k-mer order per branch, the reference's float32 sums bit for bit (PlacementProcess.java:719-735);
+//   * select: one pass over the table into the stream heads (fed in slot order = any branch order: the heads keep the branch, ties
+//     inside a stream are read off the heads at the end as in place_packed16s_kernel), K rounds; a read in doubt ranks every entry at
+//     or above the K-th score exactly.
+// Reads that do not fit (more keys than the table takes, a probe batch of more units than the list, too many candidates) mark their
+// tile (PlaceArgs::tile_marks) and place_packed16w_kernel, launched behind this kernel with only_marked set, places it: results are
+// identical to the dense kernels' either way.  A tile is the four reads at slots 4t .. 4t+3 of the batch's order, taken one after
+// the other by one wave.  LDS per wave: keys[NS] | vals[NS] | items[main_cap].  DESIGN.md section 4.1d.
+// ------------------------------------------------------------------------------------------------
+template <int BITS, int U, int NPL, int PU, int LOGS>
+__global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
+    constexpr int TM = TM_COMPACT;
+    constexpr u32 NS = 1u << LOGS;
+    constexpr u32 KEY_BITS = 16u, KEY_MASK = (1u << KEY_BITS) - 1u;  // key = branch + 1 (the reference's ids are 16-bit chars below 65 535); the step stamp lives above it
+    extern __shared__ u32 lds[];
+    // LDS: [NS] the table's keys | [64] a word of every lane's own (always 0) | [NS] the table's values | [main_cap] the list
+    u32 *keys = lds;
+    u32 *vals = lds + NS + 64;
+    u32 *items = lds + 2 * NS + 64;
+    constexpr u32 VOFF = NS + 64;  // lds[VOFF + slot] = the slot's value; lds[NS + lane] = the lane's own word, for key and value operations alike
+    const bool perm_given = tile_order_given(a);
+    const u32 lane = threadIdx.x & 63;
+    const u32 gi = lane >> 4, li8 = (lane & 15u) * 8u;
+    const u32 k = a.db.k, wpr = a.words_per_read;
+    const float T = a.db.T;
+    const int K = (int)a.keep_at_most;
+    const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
+    const int cap_items = (int)a.main_cap - 12 * U * NPL - 8;  // fillers behind the last step + the read-ahead of the ring
+    const int capc = (int)(a.main_cap / 2) - 16;         // candidate keys of a read in doubt (u64), the last 16 = the winners
+    const u32 key_limit = a.work_cap;                    // keys a table takes before a step (the step adds <= 64 NPL: never full)
+#ifdef RK_STAMPS
+    unsigned long long st_[16] = {0}, t_ = rk_now();
+#endif
+    auto wave_scan = [&](u32 v, u32 &tot) {  // inclusive prefix sum over the wave's 64 lanes + the total
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+        const u32 r0 = (u32)__builtin_amdgcn_readlane((int)v, 15), r1 = (u32)__builtin_amdgcn_readlane((int)v, 31);
+        const u32 r2 = (u32)__builtin_amdgcn_readlane((int)v, 47), r3 = (u32)__builtin_amdgcn_readlane((int)v, 63);
+        v += gi >= 1 ? r0 : 0u;
+        v += gi >= 2 ? r1 : 0u;
+        v += gi >= 3 ? r2 : 0u;
+        tot = r0 + r1 + r2 + r3;
+        return v;
+    };
+
+    const u64 n_tiles = (a.n_reads + 3) / 4;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        bool handed = false;  // (wave-uniform) some read of the tile is left to place_packed16w_kernel
+        for (u32 g = 0; g < 4u; g++) {
+            const u64 slot = tile * 4 + g;
+            if (slot >= a.n_reads) break;
+            u64 r = tile_read(a, slot, perm_given);
+            r = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(r >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)r);
+            u32 R = (u32)__builtin_amdgcn_readfirstlane((int)(a.lens ? a.lens[r] : a.fixed_len));  // (wave-uniform: one read per wave)
+            const u32 fin = (u32)__builtin_amdgcn_readfirstlane((int)(a.flags_in ? a.flags_in[r] : 0u));
+            {
+                const u32 cap_syms = (wpr * 32u) / BITS;
+                R = R < cap_syms ? R : cap_syms;
+            }
+            u32 flags = fin & (RK_FLAG_BAD_CHAR | RK_FLAG_AMBIGUOUS | RK_FLAG_TOO_LONG);
+            const bool is_amb = (fin & RK_FLAG_AMBIGUOUS) != 0;
+            const bool rejected = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG)) != 0;
+            if (R < k) flags |= RK_FLAG_TOO_SHORT;
+            const u32 Q = (!is_amb && !rejected && R >= k) ? (R - k + 1) : 0u;  // sk.getMerCount() (AmbigSequenceKnife.java:191)
+            const float QT = (float)(int)Q * T;                                  // int * float (PlacementProcess.java:728)
+            const u32 *rec = a.packed + r * wpr;
+            // ---- the table: empty keys, every value the read's Q * T ----
+            {
+                uint4 *k4 = (uint4 *)keys, *v4 = (uint4 *)vals;
+                const u32 qb = __float_as_uint(QT);
+                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u), q4 = make_uint4(qb, qb, qb, qb);
+#pragma unroll
+                for (u32 i = 0; i < NS / 4u / 64u; i++) {
+                    k4[i * 64u + lane] = z4;
+                    v4[i * 64u + lane] = q4;
+                }
+                keys[NS + lane] = 0u;
+            }
+            wave_lds_fence();
+            RK_STAMP(0);  // read setup + table reset
+
+            bool over = false;  // (wave-uniform) the read does not fit: table, list or candidates
+            u32 n_keys = 0;     // (wave-uniform) keys in the table
+            u32 stamp = 1;      // (wave-uniform) number of the next step
+            int cnt = 0;        // items waiting in the list
+
+            // ---- a step: this lane's entries of the step's 4 * NPL units (unit 4 p + gi of the step is entry p of the lanes of row gi).
+            //      Written without divergent control flow: lanes without an entry (padding of a unit, a filler item) work on a word
+            //      of their own behind the table, lanes that have found their slot repeat a compare-and-swap that changes nothing ----
+            auto apply = [&](const u32 (&sbv)[NPL], const float (&scv)[NPL]) {
+                if (n_keys > key_limit || stamp >= 0xFFFEu) over = true;  // (the stamp has 16 bits)
+                if (over) return;
+                // h[p]: BYTE offset of the entry's slot in the LDS (keys at 0, the lane's own word at 4 (NS + lane)).  Conditions are kept
+                // as wave masks in SGPRs and combined there (hipcc turns a bool that feeds both a select and a ballot into a 0 / 1
+                // register and a second compare): a round is 6 vector instructions an entry.
+                u32 key[NPL], h[NPL];
+                u64 act[NPL], fresh[NPL];
+                const u32 own = (NS + lane) * 4u;
+#pragma unroll
+                for (int p = 0; p < NPL; p++) {
+                    key[p] = sbv[p] >> 2;  // (branch + 1; 0 = padding of a unit, a filler item)
+                    act[p] = ~mask_eq0(key[p]);
+                    h[p] = mask_select(own, ((key[p] * 0x9E3779B1u) >> (32 - LOGS)) << 2, act[p]);
+                    fresh[p] = 0ull;
+                }
+#ifdef RK_STAMPS
+                st_[15] += 1;
+#endif
+                // Every lane that is still looking has failed in every round so far, so the distance of its next hop -- triangular
+                // probing: 1, 2, 3 ... slots, every slot is visited -- is the round's number: one scalar for the wave.
+                u32 hop4 = 0;
+                u64 pending;
+                do {
+#ifdef RK_STAMPS
+                    st_[14] += 1;
+#endif
+                    hop4 += 4u;
+                    u32 old[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) old[p] = atomicCAS((u32 *)((unsigned char *)lds + h[p]), 0u, key[p]);  // (the lane's own word: compares 0 with 0)
+                    pending = 0ull;
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        const u64 mine = mask_eq0(old[p]), ok = mine | mask_eq_lo16(old[p], key[p]);
+                        fresh[p] |= mine;
+                        pending |= ~ok;
+                        h[p] = mask_select((h[p] + hop4) & (NS * 4u - 4u), h[p], ok);
+                    }
+                } while (pending != 0ull);
+                u64 clash = 0ull;
+                {
+                    u32 prev[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) prev[p] = atomicMax((u32 *)((unsigned char *)lds + h[p]), mask_select(0u, key[p] | (stamp << KEY_BITS), act[p]));
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        n_keys += (u32)__builtin_popcountll(fresh[p] & act[p]);
+                        clash |= mask_eq0((prev[p] >> KEY_BITS) ^ stamp);  // another unit of this step updates the same branch
+                    }
+                }
+                float d[NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; p++) d[p] = scv[p] - T;
+                // (value of slot s: VOFF words behind its key; the lane's own word serves both and stays 0)
+                if (clash == 0ull) {
+                    u32 at[NPL];
+                    float v[NPL];
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        at[p] = mask_select(own, h[p] + VOFF * 4u, act[p]);
+                        v[p] = __uint_as_float(*(u32 *)((unsigned char *)lds + at[p]));
+                    }
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) *(u32 *)((unsigned char *)lds + at[p]) = mask_select(0u, __float_as_uint(v[p] + d[p]), act[p]);
+                } else {  // the step's units one after the other: k-mer order per branch
+#ifdef RK_STAMPS
+                    st_[12] += 1;
+#endif
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+#pragma unroll
+                        for (u32 t = 0; t < 4u; t++) {
+                            const u64 on = act[p] & (0xFFFFull << (16u * t));
+                            u32 *at = (u32 *)((unsigned char *)lds + mask_select(own, h[p] + VOFF * 4u, on));
+                            const float v = __uint_as_float(*at);
+                            *at = mask_select(0u, __float_as_uint(v + d[p]), on);
+                            wave_lds_fence();
+                        }
+                    }
+                }
+                stamp += 1u;
+            };
+            auto issue = [&](u32 item, u32 &b, float &v) {
+                const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(rows_rs, (int)(item + li8), 0, RK_ROW_AUX);
+                b = e.x;
+                v = __uint_as_float(e.y);
+            };
+            auto flush = [&]() {
+                const int steps = (cnt + 4 * NPL - 1) / (4 * NPL);
+                for (int i = cnt + (int)lane; i < 4 * NPL * (steps + 2 * U); i += 64) items[i] = ITEM_FILLER;
+                wave_lds_fence();
+                RK_STAMP(2);  // emit
+                const u32 *my = items + gi;  // entry p of this lane in step s: unit my[4 (NPL s + p)]
+                u32 sb[U][NPL], it[U][NPL];
+                float sc[U][NPL];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) issue(my[4 * (NPL * u + p)], sb[u][p], sc[u][p]);
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) it[u][p] = my[4 * (NPL * (U + u) + p)];
+                int s0 = 0;
+                while (true) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        apply(sb[u], sc[u]);
+#pragma unroll
+                        for (int p = 0; p < NPL; p++) {
+                            issue(it[u][p], sb[u][p], sc[u][p]);
+                            it[u][p] = my[4 * (NPL * (s0 + 2 * U + u) + p)];
+                        }
+                    }
+                    s0 += U;
+                    if (s0 >= steps) break;  // what is left in the ring are fillers
+                }
+                wave_lds_fence();
+                cnt = 0;
+                RK_STAMP(3);  // accumulate
+            };
+
+            // ---- probe + emit, PU * 64 k-mers at a time ----
+            for (u32 pos = 0; pos < Q && !over; pos += (u32)PU * 64u) {
+                u64 code[PU];
+                RawSlot raw[PU];
+                u32 nch[PU], rb[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const u32 j = pos + (u32)u * 64u + lane;
+                    code[u] = extract_code<BITS>(rec, wpr, j < Q ? j : 0u, k);
+                }
+#pragma unroll
+                for (int u = 0; u < PU; u++) raw[u] = lookup_fetch<BITS, TM>(a.db, code[u]);
+                __builtin_amdgcn_sched_barrier(0);  // all PU gathers are issued before any of them is decoded
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const u32 j = pos + (u32)u * 64u + lane;
+                    u64 d = lookup_decode<BITS, TM>(a.db, raw[u], code[u]);
+                    d = j < Q ? d : 0ull;
+                    nch[u] = (((u32)d & DESC_LEN_MASK) + 15u) >> 4;
+                    rb[u] = (u32)(d >> DESC_LEN_BITS) * 8u;  // byte offset of the row's first 128-byte unit
+                }
+                RK_STAMP(1);  // probe
+                u32 incl[PU], tot[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) incl[u] = wave_scan(nch[u], tot[u]);
+#pragma unroll 1
+                for (int u = 0; u < PU; u++) {  // (64 k-mers at a time: the list is flushed between them when it fills up; one copy of the flush's code)
+                    u32 n_u = nch[0], rb_u = rb[0], in_u = incl[0], tot_u = tot[0];
+#pragma unroll
+                    for (int w = 1; w < PU; w++) {
+                        n_u = u == w ? nch[w] : n_u; rb_u = u == w ? rb[w] : rb_u; in_u = u == w ? incl[w] : in_u; tot_u = u == w ? tot[w] : tot_u;
+                    }
+                    if (over) break;
+                    if (cnt + (int)tot_u > cap_items && cnt > 0) flush();
+                    if ((int)tot_u > cap_items) {  // rows too long for this kernel's list
+                        over = true;
+                        break;
+                    }
+                    const int base = cnt + (int)(in_u - n_u);
+                    if (n_u > 0) items[base] = rb_u;
+                    if (n_u > 1) items[base + 1] = rb_u + 128u;
+                    for (u32 c = 2; __any(c < n_u); c++)
+                        if (c < n_u) items[base + (int)c] = rb_u + c * 128u;
+                    cnt += (int)tot_u;
+                }
+            }
+            if (cnt > 0 && !over) flush();
+
+            // ---- select: the table into the stream heads ----
+            u64 acc_key = 0;
+            if (!over) {
+                Heads4 hd;
+                heads_clear(hd);
+                const uint4 *k4 = (const uint4 *)keys, *v4 = (const uint4 *)vals;
+#pragma unroll 2
+                for (u32 i = 0; i < NS / 4u / 64u; i++) {
+                    const uint4 kq = k4[i * 64u + lane], vq = v4[i * 64u + lane];
+                    heads_feed<0>(hd, kq.x ? __uint_as_float(vq.x) : -INFINITY, kq.x & KEY_MASK);  // the heads keep the slot id = branch + 1
+                    heads_feed<1>(hd, kq.y ? __uint_as_float(vq.y) : -INFINITY, kq.y & KEY_MASK);
+                    heads_feed<2>(hd, kq.z ? __uint_as_float(vq.z) : -INFINITY, kq.z & KEY_MASK);
+                    heads_feed<3>(hd, kq.w ? __uint_as_float(vq.w) : -INFINITY, kq.w & KEY_MASK);
+                }
+                RK_STAMP(4);  // table scan
+                // equal scores inside one stream arrive in table order, not in branch order: seen at the end (place_packed16s_kernel)
+                float tie_v = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bool t = hd.s1[c] != -INFINITY && (hd.s0[c] == hd.s1[c] || hd.dr[c] == hd.s1[c]);
+                    tie_v = fmaxf(tie_v, t ? hd.s1[c] : -INFINITY);
+                }
+                u32 win_o, win_i, kth_o;
+                bool d0;
+                const int num = heads_rounds_raw<64, true>(hd, K, lane, 0u, win_o, win_i, d0, &kth_o);
+                acc_key = ((int)lane < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
+                const bool tie = tie_v != -INFINITY && ord_f32(tie_v) >= kth_o;
+                RK_STAMP(5);  // rounds
+                if (d0 || __any(tie)) {
+                    // ---- a read in doubt: every entry at or above the K-th score is a candidate (the true K best are among them),
+                    //      ranked exactly (keys are unique: they embed the branch) ----
+#ifdef RK_STAMPS
+                    st_[13] += 1;
+#endif
+                    u64 *cl = (u64 *)items, *win = cl + capc;
+                    if (lane < 16u) win[lane] = 0ull;
+                    int c = 0;
+                    for (u32 i = 0; i < NS / 4u / 64u; i++) {
+                        const uint4 kq = k4[i * 64u + lane], vq = v4[i * 64u + lane];
+                        const u32 kk[4] = {kq.x, kq.y, kq.z, kq.w}, vv[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const bool cand = kk[e] != 0u && ord_f32(__uint_as_float(vv[e])) >= kth_o;
+                            const u64 bal = __ballot(cand);
+                            const int idx = c + (int)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                            if (cand && idx < capc) cl[idx] = make_key(vv[e], (kk[e] & KEY_MASK) - 1u);
+                            c += (int)__builtin_popcountll(bal);
+                        }
+                    }
+                    wave_lds_fence();
+                    if (c > capc) {
+                        over = true;
+                    } else {
+                        for (int j = (int)lane; j < c; j += 64) {
+                            const u64 mine = cl[j];
+                            int rank = 0;
+                            for (int t = 0; t < c; t++) rank += (cl[t] > mine) ? 1 : 0;
+                            if (rank < K) win[rank] = mine;
+                        }
+                        wave_lds_fence();
+                        acc_key = (int)lane < K ? win[lane] : 0ull;
+                        wave_lds_fence();
+                    }
+                    RK_STAMP(6);  // exact ranking of a read in doubt
+                }
+            }
+            if (over) {
+#ifdef RK_STAMPS
+                st_[10] += 1;
+#endif
+                handed = true;
+                continue;
+            }
+#ifdef RK_STAMPS
+            st_[11] += 1;
+#endif
+            const int numBest = __builtin_popcountll(__ballot(acc_key != 0ull));
+            const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+            // (keep_at_most <= 16: the winners sit in the wave's first 16-lane row -- the DPP form of the weighing; the other rows idle)
+            if (!deferred) weigh_and_store<16>(a, r, lane, numBest, acc_key, flags);
+            RK_STAMP(7);  // weigh + store
+        }
+        if (handed && lane == 0) a.tile_marks[tile] = 1;
+    }
+#ifdef RK_STAMPS
+    if (lane == 0 && blockIdx.x < 4096)
+        for (int i = 0; i < 16; i++) rk_stamp_buf[(u64)blockIdx.x * 16 + i] = st_[i];
 #endif
 }
 

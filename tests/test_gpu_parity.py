@@ -809,7 +809,7 @@ def test_windowed_kernel_protein_on_large_trees(n_branches):
     sdb = synth.make_db(20, 3, n_branches, 7000, 80000, seed=n_branches)
     odb = O.OracleDB.from_synth(sdb)
     db = ra.PhyloKmerDB.from_synth(sdb)
-    assert "place_packed16s_kernel<BITS=5" in db.kernel_name() and "place_packed16w_kernel" in db.kernel_name(), db.kernel_name()
+    assert ("place_hash64_kernel<BITS=5" in db.kernel_name() or "place_packed16s_kernel<BITS=5" in db.kernel_name()) and "place_packed16w_kernel" in db.kernel_name(), db.kernel_name()
     db.close()
     for length in (90, 240):
         seq, off = synth.make_reads(20, 700, length, seed=length, amb_rate=0.002, bad_rate=0.002, var_len=length // 2)
@@ -827,6 +827,7 @@ def test_sorted_stream_kernel_on_every_windowed_tree(alphabet, k, n_branches, n_
     reads with ambiguity codes / unsupported characters / ragged lengths, rows scattered over all windows (tiles it hands over to
     place_packed16w_kernel), and scores below the threshold (the general first-touch path)"""
     monkeypatch.setenv("RK_WSTREAM_ALWAYS", "1")
+    monkeypatch.setenv("RK_NO_HASH", "1")  # (round 4: place_hash64_kernel runs first where this kernel did)
     sdb = synth.make_db(alphabet, k, n_branches, n_keys, n_entries, seed=n_branches + 1)
     odb = O.OracleDB.from_synth(sdb)
     db = ra.PhyloKmerDB.from_synth(sdb)
@@ -866,21 +867,75 @@ def test_protein_records_filled_to_the_last_word(n_branches):
         assert st["placed"] > 300
 
 
+@pytest.mark.parametrize("alphabet,k,n_branches,n_keys,n_entries,length", [
+    (4, 8, 1291, 40000, 520000, 150), (4, 8, 2801, 40000, 520000, 150), (4, 8, 3999, 40000, 520000, 150), (4, 8, 7999, 40000, 520000, 150),
+    (4, 8, 15999, 50000, 650000, 160), (4, 8, 40001, 50000, 650000, 150), (4, 8, 65535, 50000, 650000, 150), (4, 7, 9001, 12000, 400000, 120),
+    (4, 8, 19999, 50000, 650000, 400), (20, 3, 3100, 6000, 60000, 90), (20, 3, 20001, 7000, 80000, 100)])
+def test_hash_kernel_on_every_windowed_tree(alphabet, k, n_branches, n_keys, n_entries, length, monkeypatch, dev_lib):
+    """place_hash64_kernel (round 4: a read's scores in an LDS hash table keyed by branch, four row units a step, the units of a step
+    one after the other whenever two of them meet in a branch) forced onto every windowed tree, for keep_at_most 1 ... 16, all
+    ambiguity modes, reads with ambiguity codes / unsupported characters / ragged lengths (400-symbol reads: records of more than 16
+    words, tables that overflow -> tiles handed to place_packed16w_kernel), rows scattered over the whole tree, scores below the
+    threshold, and a table small enough that most reads are handed over"""
+    monkeypatch.setenv("RK_HASH_ALWAYS", "1")
+    sdb = synth.make_db(alphabet, k, n_branches, n_keys, n_entries, seed=n_branches + 1)
+    odb = O.OracleDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    assert "place_hash64_kernel" in db.kernel_name(), db.kernel_name()
+    db.close()
+    seq, off = synth.make_reads(alphabet, 3000, length, seed=n_branches, amb_rate=0.001, bad_rate=0.002, var_len=length // 2)
+    for K, amb in ((7, "mean"), (1, "skip"), (3, "max"), (12, "mean"), (16, "skip")):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, amb, keepAtMost=K)
+        assert st["placed"] > 2000
+    import dataclasses
+    sc = sdb.scores.copy()
+    sc[::3] = sc[::3] + np.float32(sdb.thr_log10)
+    low = dataclasses.replace(sdb, scores=sc)
+    run_case(low, O.OracleDB.from_synth(low), seq, off, "direct", 0, "mean")
+    if alphabet == 4:
+        scat = _scatter_rows(synth.make_db(4, 7, n_branches, 12000, 150000, seed=length), seed=n_branches)
+        s2, o2 = synth.make_reads(4, 600, length, seed=3)
+        run_case(scat, O.OracleDB.from_synth(scat), s2, o2, "direct", 0, "mean")
+        monkeypatch.setenv("RK_HASH_KEY_SLACK", "1400")  # a table of 648 keys: most reads overflow it, some in the middle of a step
+        run_case(sdb, odb, seq, off, "direct", 0, "mean")
+
+
+@pytest.mark.parametrize("n_branches", [2801, 9001, 65535])
+def test_hash_kernel_units_of_a_step_that_meet_in_a_branch(n_branches, monkeypatch, dev_lib):
+    """clade-shaped reads: consecutive k-mers hit the same few dozen branches, so nearly every step of place_hash64_kernel holds two
+    units that update the same branch and is applied unit by unit -- float32 sums in k-mer order, bit for bit; mixed with uniform
+    reads (steps without a clash) in one batch, re-tiled"""
+    monkeypatch.setenv("RK_HASH_ALWAYS", "1")
+    monkeypatch.setenv("RK_RETILE_MIN_READS", "0")
+    sdb, genome = _clade_db(9, n_branches, 6000, seed=n_branches, mean_row=20.0)
+    odb = O.OracleDB.from_synth(sdb)
+    s1, o1 = synth.make_motif_reads(genome, 2000, 150, seed=5, amb_rate=0.001, var_len=40)
+    s2, o2 = synth.make_reads(4, 501, 150, seed=6, var_len=100)
+    seq = np.concatenate([s1, s2])
+    off = np.concatenate([o1, o2[1:] + o1[-1]])
+    for K in (7, 16):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K, keepFactor=0.0)
+        assert st["placed"] > 1900
+
+
+@pytest.mark.parametrize("kernel", ["hash", "sorted"])
 @pytest.mark.parametrize("seed", range(6 + _EXTRA_SEEDS))
-def test_sorted_stream_kernel_with_scores_from_a_handful_of_values(seed):
+def test_short_row_kernels_of_big_trees_with_scores_from_a_handful_of_values(seed, kernel, request, monkeypatch):
     """equal sums everywhere: every score of the database is one of eight values (dyadic fractions of the threshold, so that sums of
     them collide exactly), on windowed trees of 4 501 ... 65 535 branches, keep_at_most 1 ... 16.  The stream heads of
-    place_packed16s_kernel are fed in any slot order; a tie that could be among the K best has to send the tile through the exact
-    second pass (or to place_packed16w_kernel) -- the result must be the oracle's branch for branch wherever the oracle's own order is
-    defined (tests/util.py compares exact ties as sets)."""
+    place_hash64_kernel (the product's choice beyond 28 000 branches; RK_HASH_ALWAYS) and of place_packed16s_kernel (RK_NO_HASH) are fed in any branch order; a tie that
+    could be among the K best has to send the read through the exact ranking (or to place_packed16w_kernel) -- the result must be the
+    oracle's branch for branch wherever the oracle's own order is defined (tests/util.py compares exact ties as sets)."""
     import dataclasses
+    request.getfixturevalue("dev_lib")
+    monkeypatch.setenv("RK_NO_HASH" if kernel == "sorted" else "RK_HASH_ALWAYS", "1")
     rng = np.random.default_rng(1000 + seed)
     nb = int(rng.choice([4501, 7000, 9001, 15999, 20001, 33001, 65535]))
     sdb = synth.make_db(4, 8, nb, 40000, 520000, seed=seed)
     q = (rng.integers(1, 9, sdb.scores.shape[0]).astype(np.float32) / np.float32(8.0)) * np.float32(sdb.thr_log10)
     sdb = dataclasses.replace(sdb, scores=q.astype(np.float32))
     db = ra.PhyloKmerDB.from_synth(sdb)
-    assert "place_packed16s_kernel" in db.kernel_name(), db.kernel_name()
+    assert ("place_hash64_kernel" if kernel == "hash" else "place_packed16s_kernel") in db.kernel_name(), db.kernel_name()
     db.close()
     seq, off = synth.make_reads(4, 2500, 150, seed=seed, var_len=70)
     K = int(rng.choice([1, 3, 7, 8, 12, 16]))
