@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RK_VERSION 100 /* 0.1.0 */
+#define RK_VERSION 101 /* 0.1.1: rk_db_save / rk_db_save_desc / rk_db_load / rk_db_image_info / rk_db_image_user, RK_ERR_IO */
 
 /* alphabets = number of unambiguous states (States.getNonAmbiguousStatesCount()) */
 #define RK_ALPHABET_DNA 4  /* src/core/DNAStatesShifted.java : A=0 T/U=1 C=2 G=3, 2 bits/base   */
@@ -66,6 +66,7 @@ extern "C" {
 #define RK_ERR_HIP -3
 #define RK_ERR_NOMEM -4
 #define RK_ERR_UNSUPPORTED -5
+#define RK_ERR_IO -6 /* a database image file could not be read / written, or failed its size / checksum tests */
 
 typedef struct rk_db rk_db;
 
@@ -132,6 +133,25 @@ void rk_db_destroy(rk_db *db);
  * does after the first rk_db_create, and the only way to replicate an image that exists in HBM only (rk_db_create_synth). */
 int rk_db_clone(const rk_db *src, int32_t device, rk_db **out);
 int rk_db_get_info(const rk_db *db, rk_db_info *info);
+
+/* The database as a file: the HBM image exactly as the kernels read it (k-mer table, row blob, window spans) behind a fixed header,
+ * so that loading is mmap + one host-to-device copy per section -- no parse, no rebuild.  Stands where the reference stores and
+ * reloads its Java-serialised session (src/main_v2/SessionNext_v2.java:110-154 storeHash, :158-207 load); only the lookup structure
+ * and the scalars of rk_db_desc are kept -- whatever else the caller needs next to it (rk_place: the reference tree) travels as an
+ * opaque `user` blob the engine never looks inside.
+ *   rk_db_save        a handle's image, read back from the device.
+ *   rk_db_save_desc   the same file from the caller's CSR arrays, built on the host: no device is touched (desc->device is ignored).
+ *   rk_db_load        a new handle on `device`; size, header and payload checksums are verified before the device is looked at, a
+ *                     truncated / overwritten / bit-flipped file is refused with RK_ERR_IO.  (Integrity, not authenticity: an image
+ *                     is trusted input, like the library itself.)
+ *   rk_db_image_info  the same checks without a device; info (device = -1) and the user blob's length, either may be NULL.
+ *   rk_db_image_user  the user blob: at most `cap` bytes into buf, *len = its full length.
+ * Files are little-endian and specific to the image version this library writes (a newer / older file is refused, not guessed at). */
+int rk_db_save(const rk_db *db, const char *path, const void *user, uint64_t user_bytes);
+int rk_db_save_desc(const rk_db_desc *desc, const char *path, const void *user, uint64_t user_bytes);
+int rk_db_load(const char *path, int32_t device, rk_db **out);
+int rk_db_image_info(const char *path, rk_db_info *info, uint64_t *user_bytes);
+int rk_db_image_user(const char *path, void *buf, uint64_t cap, uint64_t *len);
 
 /* One row read back out of the HBM image through the same table lookup and entry decode the placement kernels use:
  * the engine's counterpart of CustomHash_v4_FastUtil81.getPairsOfTopPosition2 (src/core/hash/CustomHash_v4_FastUtil81.java:146-153;
@@ -206,7 +226,11 @@ int rk_pack_reads_device(rk_db *db, uint64_t n_reads, const uint8_t *d_seq_ascii
                          void *stream);
 /* rk_place_packed_device: d_lens may be NULL (every read has fixed_len symbols); d_flags_in may be NULL
  * (no read carries BAD_CHAR/AMBIGUOUS).  Reads flagged AMBIGUOUS need d_seq_ascii/d_seq_off (else they are
- * reported unplaced with the flag set).  Asynchronous on `stream`. */
+ * reported unplaced with the flag set).  Asynchronous on `stream`.  d_flags_in may be the output flag array itself (in place).
+ * What the call allocates: nothing from the device's memory pools; the handle keeps one grow-only scratch block per stream it has
+ * been launched on (the order the kernels take a large batch's reads in, the marks of tiles one kernel hands to the next: ~5 bytes a
+ * read, plain hipMalloc, freed by rk_db_destroy) -- so calls on ONE stream must not overlap in time from different threads, and a
+ * call made while the stream is being captured into a graph does without the block if it would have to grow. */
 int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_reads, const uint32_t *d_packed,
                            uint32_t words_per_read, const uint32_t *d_lens, uint32_t fixed_len,
                            const uint32_t *d_flags_in, const uint8_t *d_seq_ascii, const uint64_t *d_seq_off,

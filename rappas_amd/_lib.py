@@ -10,7 +10,7 @@ RK_ALPHABET_DNA, RK_ALPHABET_AA = 4, 20
 RK_AMB_SKIP, RK_AMB_MEAN, RK_AMB_MAX = 0, 1, 2
 RK_TABLE_AUTO, RK_TABLE_HASH, RK_TABLE_DIRECT, RK_TABLE_DIRECT8 = 0, 1, 2, 4
 RK_FLAG_PLACED, RK_FLAG_BAD_CHAR, RK_FLAG_TOO_SHORT, RK_FLAG_AMBIGUOUS, RK_FLAG_BELOW_NSBOUND, RK_FLAG_TOO_LONG = 1, 2, 4, 8, 16, 64
-RK_OK, RK_ERR_INVALID, RK_ERR_NO_DEVICE, RK_ERR_HIP, RK_ERR_NOMEM, RK_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+RK_OK, RK_ERR_INVALID, RK_ERR_NO_DEVICE, RK_ERR_HIP, RK_ERR_NOMEM, RK_ERR_UNSUPPORTED, RK_ERR_IO = 0, -1, -2, -3, -4, -5, -6
 
 
 class rk_db_desc(C.Structure):
@@ -78,6 +78,11 @@ EXPORTS = {
     "rk_db_destroy": (None, [C.c_void_p]),
     "rk_db_clone": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "rk_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(rk_db_info)]),
+    "rk_db_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
+    "rk_db_save_desc": (C.c_int, [C.POINTER(rk_db_desc), C.c_char_p, C.c_void_p, C.c_uint64]),
+    "rk_db_load": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rk_db_image_info": (C.c_int, [C.c_char_p, C.POINTER(rk_db_info), C.POINTER(C.c_uint64)]),
+    "rk_db_image_user": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rk_db_fetch_row": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rk_db_create_synth": (C.c_int, [C.POINTER(rk_synth_desc), C.POINTER(C.c_void_p)]),
     "rk_place_batch": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_void_p,

@@ -99,7 +99,7 @@ def check_isa(so, verbose=False):
 
 
 HOST_BIN = os.path.join(ROOT, "rappas_amd", "bin", "rk_place")
-HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("rk_place_main.cpp", "rk_hostio.hpp", "rk_javaser.hpp")]
+HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("rk_place_main.cpp", "rk_hostio.hpp", "rk_javaser.hpp", "rk_fastio.hpp")]
 
 
 def build_host_tools(force=False, verbose=False):
@@ -109,7 +109,7 @@ def build_host_tools(force=False, verbose=False):
         return HOST_BIN
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
-    cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", HOST_BIN, HOST_SRC[0], "-L" + os.path.dirname(ENGINE_SO),
+    cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-o", HOST_BIN, HOST_SRC[0], "-L" + os.path.dirname(ENGINE_SO),
            "-lrappas_place", "-Wl,-rpath,$ORIGIN/.."]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -76,6 +76,30 @@ def validate_db(alphabet, k, n_branches, thr_log10, thr, key_codes, row_offsets,
     return info
 
 
+def save_db_image(path, alphabet, k, n_branches, thr_log10, thr, key_codes, row_offsets, branch_ids, scores, table_mode=RK_TABLE_AUTO,
+                  convert_uo=False, user=b""):
+    """rk_db_save_desc: the image file of a database given as CSR arrays, built on the host (no GPU needed)."""
+    lib = _lib.load()
+    key_codes = np.ascontiguousarray(key_codes, dtype=np.uint64)
+    row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+    branch_ids = np.ascontiguousarray(branch_ids, dtype=np.uint16)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    d = rk_db_desc(alphabet, int(bool(convert_uo)), k, n_branches, float(thr_log10), float(thr), key_codes.shape[0],
+                   _ptr(key_codes), _ptr(row_offsets), _ptr(branch_ids), _ptr(scores), 0, table_mode)
+    user = bytes(user)
+    _lib.check(lib.rk_db_save_desc(C.byref(d), str(path).encode(), user, len(user)))
+
+
+def db_image_info(path):
+    """rk_db_image_info + rk_db_image_user: (rk_db_info, user blob) of an image file after its size / checksum tests; no GPU needed."""
+    lib = _lib.load()
+    info, n = rk_db_info(), C.c_uint64(0)
+    _lib.check(lib.rk_db_image_info(str(path).encode(), C.byref(info), C.byref(n)))
+    buf = C.create_string_buffer(max(1, n.value))
+    _lib.check(lib.rk_db_image_user(str(path).encode(), buf, n.value, C.byref(n)))
+    return info, buf.raw[:n.value]
+
+
 class PhyloKmerDB:
     """Phylo-kmer DB resident in one GPU's HBM (open-addressed / direct table + CSR rows)."""
 
@@ -111,6 +135,24 @@ class PhyloKmerDB:
         d = _lib.rk_synth_desc(spec.alphabet, int(bool(convert_uo)), spec.k, spec.n_branches, float(spec.thr_log10), float(spec.thr),
                                int(spec.seed) & 0xFFFFFFFFFFFFFFFF, float(spec.key_fraction), float(spec.mean_row_len), device, table_mode)
         _lib.check(self._lib.rk_db_create_synth(C.byref(d), C.byref(self._h)))
+        info = rk_db_info()
+        _lib.check(self._lib.rk_db_get_info(self._h, C.byref(info)))
+        self.info = info
+        return self
+
+    def save(self, path, user=b""):
+        """rk_db_save: this handle's HBM image as a file (the reference's SessionNext_v2.storeHash, SessionNext_v2.java:110-154);
+        `user` = bytes the caller wants next to it (the tools keep the reference tree there)."""
+        user = bytes(user)
+        _lib.check(self._lib.rk_db_save(self.handle, str(path).encode(), user, len(user)))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """rk_db_load: a handle from an image file -- mmap + one upload per section, no rebuild (SessionNext_v2.load, :158-207)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.rk_db_load(str(path).encode(), device, C.byref(self._h)))
         info = rk_db_info()
         _lib.check(self._lib.rk_db_get_info(self._h, C.byref(info)))
         self.info = info

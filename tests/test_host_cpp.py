@@ -166,3 +166,84 @@ def test_union_reader_rejects_what_is_not_a_union(rk_place, tmp_path):
             assert "nested more than" in r.stderr
         with pytest.raises(ValueError):
             hostio.load_uniondb(blob)
+
+
+# ---- round 4: the all-threads host path of rk_place (rk_fastio.hpp) is held to the one-string-at-a-time path above ----
+def _messy_fasta(rng, n, dup_every=5, multiline=True, weird_names=False):
+    """records with duplicates (incl. gap variants: the checksum strips '-'), blank / '#' / CRLF lines, multi-line sequences, leading
+    and trailing blanks, headers with spaces, an empty sequence, text before the first record"""
+    seqs = ["".join("ACGT"[int(b)] for b in rng.integers(0, 4, int(rng.integers(20, 220)))) for _ in range(n)]
+    lines = ["stray line before any record", "", "# a comment"]
+    for i in range(n):
+        s = seqs[i]
+        if i % dup_every == 3:
+            s = seqs[int(rng.integers(0, i))]                      # a duplicate of an earlier read
+            if i % 2:
+                s = s[:7] + "-" + s[7:] + "--"                       # ... written with gaps
+        name = f"read{i} sample={i % 3} len={len(s)}"
+        if weird_names and i % 11 == 0:
+            name = f"odd]name}},{{{i}],\"x\" [a],[b] /slash \\ back"
+        lines.append(">" + name + ("\r" if i % 7 == 0 else ""))
+        if i == 17:
+            continue                                                # header only: an empty sequence
+        if multiline and i % 3 == 0:
+            w = int(rng.integers(10, 60))
+            parts = [s[j:j + w] for j in range(0, len(s), w)]
+            for j, part in enumerate(parts):
+                lines.append(("  " if j == 0 and i % 6 == 0 else "") + part + ("\r" if i % 7 == 0 else ""))
+                if j == 0 and i % 9 == 0:
+                    lines += ["", "# inside a record"]
+        else:
+            lines.append(s + (" \t" if i % 4 == 0 else ""))
+    return "\n".join(lines) + ("\n" if n % 2 else "")
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+@pytest.mark.parametrize("md5", [False, True])
+def test_fast_scan_and_dedup_equal_the_classic_path(rk_place, tmp_path, threads, md5):
+    rng = np.random.default_rng(threads)
+    f = tmp_path / "q.fa"
+    f.write_text(_messy_fasta(rng, 700))
+    classic = run(rk_place, "--dedup", str(f))
+    fast = run(rk_place, "--threads", str(threads), *(["--md5-dedup"] if md5 else []), "--dedup-fast", str(f))
+    assert fast == classic and classic.count("\n") < 700 and classic.count("\t") == 700
+    # one long record, no trailing newline, a file of comments only
+    (tmp_path / "one.fa").write_text(">only\nACGT\nAC-GT")
+    assert run(rk_place, "--threads", str(threads), "--dedup-fast", str(tmp_path / "one.fa")) == run(rk_place, "--dedup", str(tmp_path / "one.fa")) == "ACGTAC-GT\tonly\n"
+    (tmp_path / "none.fa").write_text("# nothing\n\n")
+    assert run(rk_place, "--threads", str(threads), "--dedup-fast", str(tmp_path / "none.fa")) == ""
+
+
+@pytest.mark.parametrize("threads,guppy,K,weird", [(1, False, 7, False), (4, False, 7, False), (7, True, 3, False), (5, False, 16, True), (2, True, 1, True)])
+def test_fast_jplace_writer_equals_the_classic_document(rk_place, tmp_path, threads, guppy, K, weird):
+    """the text the reference's seven regex replacements leave (Main_PLACEMENT_v07.java:301-315), emitted directly by every thread for
+    a range of reads, against the whole-document path; headers that the replacements could reach into take the exact path"""
+    rng = np.random.default_rng(K + threads)
+    f, t = tmp_path / "q.fa", tmp_path / "t.nwk"
+    f.write_text(_messy_fasta(rng, 900, weird_names=weird))
+    t.write_text(synth.make_newick(120, seed=K))
+    a, b = tmp_path / "fast.jplace", tmp_path / "classic.jplace"
+    for seed in (1, 2):
+        out = run(rk_place, "--threads", str(threads), "--keep-at-most", str(K), *(["--guppy-compat"] if guppy else []),
+                  "--write-selftest", str(f), str(t), str(a), str(b), str(seed)).split()
+        assert a.read_bytes() == b.read_bytes()
+        assert out[2] == ("exact" if weird else "direct") and int(out[1]) > 150
+    # nothing placed at all
+    (tmp_path / "e.fa").write_text("# empty\n")
+    run(rk_place, "--write-selftest", str(tmp_path / "e.fa"), str(t), str(a), str(b), "3")
+    assert a.read_bytes() == b.read_bytes()
+
+
+def test_database_image_from_the_tool_without_a_gpu(rk_place, tmp_path):
+    """rk_place --jsondb ... --save-dbimage: the image is built on the host (rk_db_save_desc) and carries the reference tree"""
+    import rappas_amd as ra
+    db = synth.make_db(4, 6, 21, 600, 4000, seed=8)
+    nwk = synth.make_newick(11, seed=2)
+    tree = hostio.parse_newick(nwk)
+    assert len(tree.nodes) == 21
+    (tmp_path / "db.json").write_text(hostio.dump_jsondb(db, nwk))
+    img = tmp_path / "db.rkimg"
+    subprocess.run([rk_place, "--jsondb", str(tmp_path / "db.json"), "--save-dbimage", str(img)], check=True, capture_output=True)
+    info, blob = ra.db_image_info(str(img))
+    assert (info.k, info.n_branches, info.n_keys, info.n_entries) == (6, 21, db.n_keys, db.n_entries)
+    assert blob.startswith(b"RKTREE 1 21 0\n") and blob.count(b"\n") == 22
