@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RK_VERSION 101 /* 0.1.1: rk_db_save / rk_db_save_desc / rk_db_load / rk_db_image_info / rk_db_image_user, RK_ERR_IO */
+#define RK_VERSION 101 /* 0.1.1: rk_db_save / rk_db_save_desc / rk_db_load / rk_db_image_info / rk_db_image_user, rk_reserve_host_path, RK_ERR_IO */
 
 /* alphabets = number of unambiguous states (States.getNonAmbiguousStatesCount()) */
 #define RK_ALPHABET_DNA 4  /* src/core/DNAStatesShifted.java : A=0 T/U=1 C=2 G=3, 2 bits/base   */
@@ -181,6 +181,11 @@ int rk_db_create_synth(const rk_synth_desc *desc, rk_db **out);
  * Internally: H2D, device-side pack, placement kernel(s), D2H; chunked to bound device memory. */
 int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                    const uint64_t *seq_off, rk_result *out, rk_counters *counters);
+
+/* Optional: sets up ahead of time what the first rk_place_batch / rk_place_batch_packed of a handle otherwise sets up on its way
+ * (streams, device buffers and page-locked staging for full chunks of reads of up to max_read_len symbols: ~80 ms), e.g. while the
+ * caller is still reading its input.  Nothing is placed. */
+int rk_reserve_host_path(rk_db *db, uint32_t keep_at_most, uint32_t max_read_len);
 
 /* The same for reads the host has already packed (2 bits per base / 5 per residue, symbol i at bits [i*b, (i+1)*b) of the
  * record's little-endian bit string -- the layout rk_pack_reads_device produces): 38 instead of 150 bytes per 150-bp read cross

@@ -87,6 +87,7 @@ EXPORTS = {
     "rk_db_create_synth": (C.c_int, [C.POINTER(rk_synth_desc), C.POINTER(C.c_void_p)]),
     "rk_place_batch": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.POINTER(rk_result), C.POINTER(rk_counters)]),
+    "rk_reserve_host_path": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rk_place_batch_packed": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rk_result), C.POINTER(rk_counters)]),
     "rk_pack_reads_host": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,

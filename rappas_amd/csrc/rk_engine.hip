@@ -2243,6 +2243,55 @@ done:
     return RK_OK;
 }
 
+// What the first rk_place_batch / rk_place_batch_packed of a handle would set up on its way -- the four workspaces' streams, device
+// buffers and page-locked staging buffers for full chunks of reads of up to max_read_len symbols, the launches' scratch -- done ahead
+// of time (a caller does this while it is still reading its input: ~80 ms that the first batch then does not pay).
+extern "C" int rk_reserve_host_path(rk_db *db, uint32_t keep_at_most, uint32_t max_read_len) {
+    if (!db) return fail(RK_ERR_INVALID, "rk_reserve_host_path: null handle");
+    if (keep_at_most < 1 || keep_at_most > 16) return fail(RK_ERR_INVALID, "keep_at_most=%u outside 1..16", keep_at_most);
+    RK_GUARD_BEGIN
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+    {
+    std::lock_guard<std::mutex> lock(db->host_mutex);
+    HIP_TRY(hipSetDevice(db->info.device));
+    const uint64_t n = 1ull << 18, K = keep_at_most;  // (place_host's chunk)
+    const uint32_t wpr = rk_packed_words(db, max_read_len ? max_read_len : 1);
+    const size_t pb = (size_t)n * wpr * 4;
+    const NodeCpus *node = &gpu_node_cpus(db->info.device);
+    const int device = db->info.device;
+    for (rk_workspace &w : db->ws) {
+        if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        int rc;
+        if ((rc = w.packed.reserve(pb)) || (rc = w.lens.reserve(n * 4)) || (rc = w.flags.reserve(n * 4)) || (rc = w.nrows.reserve(n)) || (rc = w.branch.reserve(n * K * 2)) ||
+            (rc = w.score.reserve(n * K * 4)) || (rc = w.lwr.reserve(n * K * 8)) || (rc = w.oflags.reserve(n * 4)) || (rc = w.h_packed.reserve(pb + 8 * n, node, device)) ||
+            (rc = w.h_nrows.reserve(n, node, device)) || (rc = w.h_branch.reserve(n * K * 2, node, device)) || (rc = w.h_score.reserve(n * K * 4, node, device)) ||
+            (rc = w.h_lwr.reserve(n * K * 8, node, device)) || (rc = w.h_oflags.reserve(n * 4, node, device)))
+            return rc;
+        (void)launch_scratch(db, w.stream, 1024 + (size_t)n / 4 + 256 + (size_t)n * 5 + 512);
+    }
+    }
+    {
+        // ... and one small batch through the whole path: the runtime loads a kernel's code to the device at its first launch
+        // (tens of milliseconds for the packer, the placement kernel and the tile-order pre-pass together)
+        const uint64_t m = 32768;  // (the pre-pass starts at this many reads)
+        const uint32_t len = std::max<uint32_t>(db->info.k, std::min<uint32_t>(max_read_len ? max_read_len : 1u, 64u));
+        std::vector<uint8_t> seq((size_t)m * len, db->info.alphabet == RK_ALPHABET_DNA ? (uint8_t)'A' : (uint8_t)'R');
+        std::vector<uint64_t> off(m + 1);
+        for (uint64_t i = 0; i <= m; i++) off[i] = i * len;
+        std::vector<uint8_t> n_rows(m);
+        std::vector<uint16_t> branch(m * keep_at_most);
+        std::vector<float> score(m * keep_at_most);
+        std::vector<double> lwr(m * keep_at_most);
+        std::vector<uint32_t> flags(m);
+        rk_result res{n_rows.data(), branch.data(), score.data(), lwr.data(), flags.data()};
+        rk_params p{keep_at_most, 0.01f, RK_AMB_MEAN, -INFINITY};
+        return rk_place_batch(db, &p, m, seq.data(), off.data(), &res, nullptr);
+    }
+    RK_GUARD_END("rk_reserve_host_path")
+}
+
 extern "C" int rk_place_batch(rk_db *db, const rk_params *p, uint64_t n_reads, const uint8_t *seq_ascii,
                               const uint64_t *seq_off, rk_result *out, rk_counters *counters) {
     if (!db || !out) return fail(RK_ERR_INVALID, "rk_place_batch: null argument");

@@ -110,6 +110,39 @@ class Tree:
         return write_newick(self, True, True, True)
 
 
+def tree_to_blob(tree):
+    """the reference tree as the `user` blob of a database image (rk_db_save): exact, line based -- the twin of rkh::tree_to_blob
+    (rappas_amd/csrc/host/rk_fastio.hpp):  RKTREE 1 <nodes> <root> / <id> <parent> <jplace edge> <float32 bits, hex> <n children> <ids...> TAB <label>"""
+    out = [f"RKTREE 1 {len(tree.nodes)} {tree.root.id}\n"]
+    for n in tree.nodes:
+        bits = int(np.float32(n.bl).view(np.uint32))
+        kids = "".join(f" {c.id}" for c in n.children)
+        out.append(f"{n.id} {n.parent.id if n.parent is not None else -1} {n.jplace_edge} {bits:08x} {len(n.children)}{kids}\t{n.label}\n")
+    return "".join(out).encode("utf-8")
+
+
+def tree_from_blob(blob):
+    text = blob.decode("utf-8")
+    lines = text.split("\n")
+    head = lines[0].split()
+    if len(head) != 4 or head[0] != "RKTREE" or head[1] != "1":
+        raise ValueError("database image carries no reference tree (RKTREE blob)")
+    n_nodes, root = int(head[2]), int(head[3])
+    nodes = [Node(i) for i in range(n_nodes)]
+    for i in range(n_nodes):
+        nums, label = lines[1 + i].split("\t", 1)
+        f = nums.split()
+        if int(f[0]) != i:
+            raise ValueError("database image: malformed tree line")
+        n = nodes[i]
+        n.parent = nodes[int(f[1])] if int(f[1]) >= 0 else None
+        n.jplace_edge = int(f[2])
+        n.bl = np.array([int(f[3], 16)], dtype=np.uint32).view(np.float32)[0]
+        n.children = [nodes[int(c)] for c in f[5:5 + int(f[4])]]
+        n.label = label
+    return Tree(nodes[root], nodes)
+
+
 def parse_newick(s):
     """NewickReader.java:46-200: an internal node gets its id when its '(' is read, a leaf when its text ends; ids are
     therefore the pre-order numbering with the root = 0.  `label:length` is split at ':' (float32 length)."""

@@ -15,12 +15,25 @@ from ..placement import PhyloKmerDB, PlacementProcess
 
 
 def place_file(db_text, fasta_text, keep_at_most=7, keep_factor=0.01, amb="mean", ns_bound=float("-inf"), guppy=False,
-               call_string="", device=0, union=False):
-    """db_text: the bytes of a --jsondb dump, or (union=True) of a Java-serialized .union database"""
-    d = hostio.load_uniondb(db_text) if union else hostio.load_jsondb(db_text)
-    tree = d["tree"]
-    db = PhyloKmerDB(d["alphabet"], d["k"], d["n_branches"], d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"],
-                     d["branch_ids"], d["scores"], device=device, convert_uo=d.get("convert_uo", False))
+               call_string="", device=0, union=False, dbimage=None, save_dbimage=None):
+    """db_text: the bytes of a --jsondb dump, or (union=True) of a Java-serialized .union database; or dbimage = the path of the
+    engine's own image file (rk_db_load: mmap + upload, the reference tree in its user blob)"""
+    if dbimage is not None:
+        from ..placement import db_image_info
+        _, blob = db_image_info(dbimage)
+        tree = hostio.tree_from_blob(blob)
+        db = PhyloKmerDB.load(dbimage, device=device)
+        if db.info.n_branches != len(tree.nodes):
+            raise ValueError("database image: tree and database disagree on the number of branches")
+    else:
+        d = hostio.load_uniondb(db_text) if union else hostio.load_jsondb(db_text)
+        tree = d["tree"]
+        if save_dbimage is not None:
+            from ..placement import save_db_image
+            save_db_image(save_dbimage, d["alphabet"], d["k"], d["n_branches"], d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"],
+                          d["branch_ids"], d["scores"], convert_uo=d.get("convert_uo", False), user=hostio.tree_to_blob(tree))
+        db = PhyloKmerDB(d["alphabet"], d["k"], d["n_branches"], d["thr_log10"], d["thr"], d["key_codes"], d["row_offsets"],
+                         d["branch_ids"], d["scores"], device=device, convert_uo=d.get("convert_uo", False))
     try:
         records = hostio.read_fasta(fasta_text)
         unique, names = hostio.dedup_reads(records)
@@ -40,6 +53,8 @@ def main(argv=None):
     g = ap.add_mutually_exclusive_group(required=True)
     g.add_argument("--jsondb", help="database dump written by the reference's --jsondb")
     g.add_argument("--uniondb", help="the reference's own database file (DB.union, Java serialization; SessionNext_v2.java:109-207)")
+    g.add_argument("--dbimage", help="the engine's own database image (written by --save-dbimage / rk_db_save): mmap + upload, no parse")
+    ap.add_argument("--save-dbimage", default=None, help="with --jsondb / --uniondb: also write the database as an image file")
     ap.add_argument("--fasta", required=True, help="query reads (-q)")
     ap.add_argument("--out", required=True, help="output .jplace")
     ap.add_argument("--keep-at-most", type=int, default=7)
@@ -50,13 +65,15 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--logs", default=None, help="directory of notplaced_<query>.tsv (default: logs/ next to --out, like the reference's workdir/logs)")
     a = ap.parse_args(argv)
-    with open(a.jsondb or a.uniondb, "rb") as f:
-        db_text = f.read()
+    db_text = None
+    if a.dbimage is None:
+        with open(a.jsondb or a.uniondb, "rb") as f:
+            db_text = f.read()
     with open(a.fasta, "rb") as f:
         fasta_text = f.read()
     call = "".join(" " + x for x in (argv if argv is not None else sys.argv[1:]))
     doc, res = place_file(db_text, fasta_text, a.keep_at_most, a.keep_factor, a.amb, a.nsbound, a.guppy_compat, call,
-                          a.device, union=a.uniondb is not None)
+                          a.device, union=a.uniondb is not None, dbimage=a.dbimage, save_dbimage=a.save_dbimage)
     with open(a.out, "w") as f:
         f.write(doc)
     logs = a.logs if a.logs is not None else os.path.join(os.path.dirname(os.path.abspath(a.out)), "logs")

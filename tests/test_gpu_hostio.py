@@ -113,6 +113,33 @@ def test_native_driver_writes_the_same_jplace(tmp_path, extra):
     assert r.returncode == 0, r.stderr
     cpp = (tmp_path / "out.jplace").read_bytes()
     assert cpp == py and len(py) > 10000
+    # rk_place's default is the all-threads host path (rk_fastio.hpp); the one-string-at-a-time path, MD5 digests for the dedup
+    # (the reference's), other thread counts: the same file
+    import re
+    no_call = lambda b: re.sub(rb'"invocation":"[^"]*"', b'"invocation":""', b)  # (the jplace records its own command line)
+    for more in (["--classic-io"], ["--md5-dedup", "--threads", "3"], ["--threads", "1"], ["--threads", "11", "--timing"]):
+        (tmp_path / "out.jplace").unlink()
+        r = subprocess.run([exe] + args + more, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert no_call((tmp_path / "out.jplace").read_bytes()) == no_call(py), more
+    assert json.loads(r.stdout.splitlines()[-1])["reads"] == 330
+    # ... and from the engine's own image file (written without a device by one tool, by the other from its handle): the only
+    # difference is the invocation string the jplace records
+    img = tmp_path / "db.rkimg"
+    r = subprocess.run([exe, "--jsondb", str(tmp_path / "db.json"), "--save-dbimage", str(img)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    iargs = ["--dbimage", str(img), "--fasta", str(tmp_path / "q.fasta"), "--out", str(tmp_path / "img.jplace")] + extra
+    assert place_tool.main(iargs) == 0
+    py_img = (tmp_path / "img.jplace").read_bytes()
+    (tmp_path / "img.jplace").unlink()
+    r = subprocess.run([exe] + iargs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "img.jplace").read_bytes() == py_img
+    strip = lambda b: json.dumps({k: v for k, v in json.loads(b).items() if k != "metadata"}, sort_keys=True)
+    assert strip(py_img) == strip(py)
+    img2 = tmp_path / "db2.rkimg"
+    assert place_tool.main(args + ["--save-dbimage", str(img2)]) == 0
+    assert img2.read_bytes() == img.read_bytes()
     # both drivers also leave logs/notplaced_<query>.tsv (PlacementProcess.java:797-806), identical
 
 

@@ -238,7 +238,7 @@ def test_database_image_from_the_tool_without_a_gpu(rk_place, tmp_path):
     """rk_place --jsondb ... --save-dbimage: the image is built on the host (rk_db_save_desc) and carries the reference tree"""
     import rappas_amd as ra
     db = synth.make_db(4, 6, 21, 600, 4000, seed=8)
-    nwk = synth.make_newick(11, seed=2)
+    nwk = synth.make_newick(21, seed=2)
     tree = hostio.parse_newick(nwk)
     assert len(tree.nodes) == 21
     (tmp_path / "db.json").write_text(hostio.dump_jsondb(db, nwk))
