@@ -46,6 +46,12 @@ def parse():
                          "falling back to none if RCCL cannot be set up; gloo = CPU tensors (rehearsals); none = no process group, "
                          "file rendezvous + CLOCK_MONOTONIC stamps (one node)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this device")
+    ap.add_argument("--single-process", action="store_true",
+                    help="add the mode RAPPAS itself would use -- ONE host process driving the GPUs: rk_db_clone to every device, one rk_place_batch_multi call per "
+                         "step over page-locked buffers -- as the field `single_process` (never `value`).  On by default when --gpus > 1 (rank 0 measures it after "
+                         "the ranks' timed region); with --gpus 1 it runs --sp-handles handles on the one device")
+    ap.add_argument("--sp-handles", type=int, default=0, help="--single-process: handles (default: --gpus; on fewer visible devices they share them round-robin)")
+    ap.add_argument("--sp-reads", type=int, default=2_000_000, help="--single-process: reads per handle and step")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher / rank bookkeeping rehearsal WITHOUT a GPU: no engine, no placement, a step is a 5 ms sleep; "
                          "the JSON line says so and carries no rate (tests of --gpus N on CPU)")
@@ -328,8 +334,9 @@ class RankSync:
         return elapsed, recs
 
     def close(self):
-        if self.world == 1:
+        if self.world == 1 or getattr(self, "_closed", False):
             return
+        self._closed = True
         if self.backend in ("nccl", "gloo"):
             try:
                 self.dist.barrier()
@@ -440,13 +447,65 @@ def launch_ranks(a):
     return rc
 
 
+def pci_bus_id(device_index):
+    """hipDeviceGetPCIBusId of a visible device ordinal ("0000:c1:00.0"): what tells N ranks on N distinct GPUs from N ranks on one"""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+            return buf.value.decode()
+    except Exception:
+        pass
+    return None
+
+
+def single_process_leg(ra, torch, db, h_seq, h_off, rlen, K, n_handles, reads_per_handle, steps=5):
+    """ONE process, n_handles device handles of the same database (rk_db_clone: device to device, over xGMI between GPUs), one
+    rk_place_batch_multi call per step: contiguous shards, one host thread per handle, no collective."""
+    n_vis = torch.cuda.device_count()
+    devices = [i % max(1, n_vis) for i in range(n_handles)]
+    clones = []
+    try:
+        t0 = time.perf_counter()
+        for dv in devices[1:]:
+            clones.append(db.clone(device=dv))
+        clone_s = time.perf_counter() - t0
+        dbs = [db] + clones
+        n = reads_per_handle * n_handles
+        base = len(h_off) - 1
+        rep = (n + base - 1) // base
+        seq = ra.host_alloc(n * rlen, np.uint8)
+        for r in range(rep):  # (the batch's own reads, repeated to the size asked for)
+            a0, a1 = r * base * rlen, min(n, (r + 1) * base) * rlen
+            seq[a0:a1] = h_seq[:a1 - a0]
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(rlen)
+        out = ra.Placements(ra.host_alloc(n, np.uint8), ra.host_alloc((n, K), np.uint16), ra.host_alloc((n, K), np.float32),
+                            ra.host_alloc((n, K), np.float64), ra.host_alloc(n, np.uint32), {})
+        pp = ra.PlacementProcess(db)
+        pp.processQueriesMulti(dbs, seq, off, keepAtMost=K, out=out)
+        pp.processQueriesMulti(dbs, seq, off, keepAtMost=K, out=out)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pp.processQueriesMulti(dbs, seq, off, keepAtMost=K, out=out)
+        dt = (time.perf_counter() - t0) / steps
+        placed = int(out.counters["placed"])
+        return {"value": n / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "handles": n_handles, "reads_per_step": n, "steps": steps,
+                "devices": devices, "device_pci_bus_ids": [pci_bus_id(dv) for dv in devices], "distinct_devices": len(set(devices)),
+                "clone_s": clone_s, "placed_per_step": placed, "entry": "rk_db_clone x (handles - 1) + rk_place_batch_multi over page-locked buffers (characters in, results out)"}
+    finally:
+        for c in clones:
+            c.close()
+
+
 def per_rank_fields(sync, recs):
     """what rank 0 adds to the JSON line about the individual ranks (their own reads/s: own reads / own time for its steps)"""
     out = {"dist_backend": sync.backend if sync.note is None else f"{sync.backend} ({sync.note})"}
     if recs and len(recs) > 1:
         rates = [r["reads_per_s"] for r in recs]
         out.update(per_rank=rates, per_rank_min=min(rates), per_rank_max=max(rates),
-                   per_rank_kernel_ms=[r["kernel_ms"] for r in recs], per_rank_device=[r.get("device_index") for r in recs])
+                   per_rank_kernel_ms=[r["kernel_ms"] for r in recs], per_rank_device=[r.get("device_index") for r in recs],
+                   per_rank_pci_bus_id=[r.get("pci_bus_id") for r in recs], distinct_gpus=len({r.get("pci_bus_id") for r in recs if r.get("pci_bus_id")}))
     return out
 
 
@@ -612,7 +671,8 @@ def main():
     kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
     # t0 .. t1 is this rank's barrier-to-barrier time (MAX over ranks = the job's time); t_own is when its own steps were done
     elapsed, per_rank = sync.finish(t0, t1, dict(reads_per_s=n_reads * a.steps / (t_own - t0), kernel_ms=kern_avg_s * 1e3,
-                                                  device=torch.cuda.get_device_name(local_rank), device_index=local_rank))
+                                                  device=torch.cuda.get_device_name(local_rank), device_index=local_rank,
+                                                  pci_bus_id=pci_bus_id(local_rank)))
 
     if rank == 0:
         value = n_gpus * n_reads * a.steps / elapsed
@@ -651,6 +711,17 @@ def main():
             "verified_vs_oracle": verified,
         }
         line.update(per_rank_fields(sync, per_rank))
+        line["n_gpus_visible"] = torch.cuda.device_count()
+        line["device_pci_bus_id"] = pci_bus_id(local_rank)
+        if (a.single_process or n_gpus > 1) and alphabet == 4 and spec is None:
+            # ---- ONE process over all GPUs (what a single JVM would do), after every rank's timed region; never `value` ----
+            sync.close()  # (the other ranks leave now: their processes must not sit in a barrier on the GPUs this leg is about to use)
+            try:
+                sp_n = min(a.sp_reads, n_reads)
+                sp_seq, sp_off = unpack_to_ascii(alphabet, packed[:sp_n].cpu().numpy().view(np.uint32), rlen)
+                line["single_process"] = single_process_leg(ra, torch, db, sp_seq, sp_off, rlen, K, a.sp_handles or n_gpus, sp_n)
+            except Exception as e:
+                line["single_process"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         pinned_bufs = None
         if not a.no_pcie and n_gpus == 1:
             # the page-locked caller buffers of the boundary legs below, allocated here, as a caller would at start-up.  (Allocated after

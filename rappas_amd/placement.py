@@ -283,15 +283,16 @@ class PlacementProcess:
         return out
 
     def processQueriesMulti(self, dbs, seq, seq_off, keepAtMost=7, keepFactor=0.01, treatAmbiguities=True,
-                            treatAmbiguitiesWithMax=False):
+                            treatAmbiguitiesWithMax=False, out=None):
         """processQueries over several device handles of the same database from this one process
         (rk_place_batch_multi: contiguous shards, one host thread per handle, no collective)."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
         n = seq_off.shape[0] - 1
         K = keepAtMost
-        out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
-                         np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
+        if out is None:
+            out = Placements(np.zeros(n, np.uint8), np.zeros((n, K), np.uint16), np.zeros((n, K), np.float32),
+                             np.zeros((n, K), np.float64), np.zeros(n, np.uint32), {})
         res = rk_result(_ptr(out.n_rows), _ptr(out.branch), _ptr(out.score), _ptr(out.lwr), _ptr(out.flags))
         p = self._params(keepAtMost, keepFactor, treatAmbiguities, treatAmbiguitiesWithMax)
         ct = rk_counters()

@@ -61,3 +61,40 @@ def test_other_configs_have_a_bench_leg(config, reads):
     assert line["config"]["workload"].startswith(config + ":")
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
     assert line["verified_vs_oracle"]["reads"] == 500
+
+
+def test_single_process_mode_and_device_identity_fields():
+    """what the first real multi-GPU record needs in order to prove N distinct GPUs (PCI bus ids per rank, visible-device count) and the
+    mode RAPPAS itself would use -- ONE process, rk_db_clone to every device, rk_place_batch_multi per step -- here with three
+    handles on the one GPU of this box; with two ranks on it, rank 0 measures the single-process mode after the ranks' timed region"""
+    common = ["--reads", "300000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pcie", "--no-clade", "--verify", "200", "--sp-reads", "150000"]
+    one = run_bench("--gpus", "1", "--single-process", "--sp-handles", "3", *common)
+    assert one["n_gpus_visible"] >= 1 and len(one["device_pci_bus_id"].split(":")) == 3
+    sp = one["single_process"]
+    assert "error" not in sp, sp
+    assert sp["handles"] == 3 and sp["reads_per_step"] == 450000 and sp["distinct_devices"] == 1 and sp["placed_per_step"] > 440000
+    assert sp["device_pci_bus_ids"] == [one["device_pci_bus_id"]] * 3 and sp["value"] > 1e7
+    two = run_bench("--gpus", "2", "--force-device", "0", "--dist-backend", "none", *common)
+    assert two["per_rank_pci_bus_id"] == [one["device_pci_bus_id"]] * 2 and two["distinct_gpus"] == 1   # (two ranks, ONE GPU: the line says so)
+    assert "error" not in two["single_process"] and two["single_process"]["handles"] == 2
+
+
+def test_device_ordinals_follow_hip_visible_devices():
+    """ordinals are positions in the list of VISIBLE devices: with HIP_VISIBLE_DEVICES=0 the one GPU is ordinal 0 and ordinal 1 does not
+    exist (rk_db_create refuses it; the engine never looks behind the runtime's remapping); the PCI bus id is the same GPU's"""
+    probe = ("import json, rappas_amd as ra; from rappas_amd import synth, _lib; import bench\n"
+             "sdb = synth.make_config_db('C1'); db = ra.PhyloKmerDB.from_synth(sdb, device=0)\n"
+             "seq, off = synth.make_reads(4, 500, 150, seed=1); n = int((ra.PlacementProcess(db).processQueries(seq, off).flags & 1).sum())\n"
+             "try:\n    ra.PhyloKmerDB.from_synth(sdb, device=1); second = 'ok'\nexcept _lib.RkError as e:\n    second = e.code\n"
+             "print(json.dumps(dict(placed=n, second=second, pci=bench.pci_bus_id(0), info_device=db.info.device)))")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    outs = []
+    for vis in (None, "0"):
+        e = dict(env)
+        if vis is not None:
+            e["HIP_VISIBLE_DEVICES"] = vis
+        p = subprocess.run([sys.executable, "-c", probe], env=e, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+    assert outs[0]["placed"] == outs[1]["placed"] > 400 and outs[0]["pci"] == outs[1]["pci"] and outs[1]["info_device"] == 0
+    assert outs[1]["second"] == -1   # RK_ERR_INVALID: device 1 is out of range when one device is visible
