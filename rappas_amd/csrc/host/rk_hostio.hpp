@@ -672,17 +672,66 @@ inline UnionDb load_uniondb(const std::string &data) {
     using rkjs::P;
     auto be32 = [](const char *b) { return (uint32_t)(uint8_t)b[0] << 24 | (uint32_t)(uint8_t)b[1] << 16 | (uint32_t)(uint8_t)b[2] << 8 | (uint32_t)(uint8_t)b[3]; };
     auto bef = [&](const char *b) { const uint32_t u = be32(b); float x; memcpy(&x, &u, 4); return x; };
-    const std::vector<rkjs::Record> recs = rkjs::parse(data);
+    // Record by record: only states (object 0), originalTree (2) and the hash (6) are kept -- the alignment, the extended tree, the AR
+    // tree and the node mapping are read (the stream has to be) and let go of at once; and the hash's rows are turned into CSR
+    // as they are read (rk_javaser.hpp: stream_annotations_of), never held as objects: a 10^7-row session loads in the memory of its
+    // CSR form plus the file (round 3: an object graph of tens of GB).
+    UnionDb db;
+    const std::string oname = "it.unimi.dsi.fastutil.objects.Object2ObjectOpenCustomHashMap", rname = "it.unimi.dsi.fastutil.chars.Char2FloatOpenHashMap";
+    uint32_t alphabet_seen = 0;
+    rkjs::Reader reader((const uint8_t *)data.data(), data.size());
+    P key_pending;
+    bool have_key = false;
+    uint64_t rows_seen = 0;
+    reader.stream_annotations_of(oname, [&](const P &x) {
+        if (!have_key) { key_pending = x; have_key = true; return; }
+        const P key = key_pending, row = x;
+        key_pending.reset();
+        have_key = false;
+        if (!key || key->kind != Node::ARRAY || !row || row->kind != Node::OBJECT) throw std::runtime_error("union: malformed entry of the outer map");
+        if (alphabet_seen == 0) throw std::runtime_error("union: the hash precedes the states object");
+        const std::string &raw = key->s;
+        uint64_t code = 0;
+        if (alphabet_seen == 4) {
+            if (raw.size() > 8) throw std::runtime_error("union: DNA key longer than 8 bytes");
+            for (size_t b = 0; b < raw.size(); b++) code |= (uint64_t)(uint8_t)raw[b] << (8 * b);  // compressMer bytes: base i at bits 2*(i%4) of byte i/4
+            if (db.k < 32 && (code >> (2 * db.k))) throw std::runtime_error("union: DNA key has bits beyond 2k");
+        } else {
+            if (raw.size() > 12) throw std::runtime_error("union: amino-acid key longer than 12 states");
+            for (size_t b = 0; b < raw.size(); b++) code |= (uint64_t)(uint8_t)raw[b] << (5 * b);
+        }
+        db.key_codes.push_back(code);
+        const P rsize = row->get("size");
+        const int64_t m = rsize ? rsize->i : -1;
+        const std::string blob = row->block(rname);
+        if (m < 0 || blob.size() != (size_t)(6 * m))
+            throw std::runtime_error("union: row announces " + std::to_string(m) + " entries, stream holds " + std::to_string(blob.size()) + " bytes");
+        for (int64_t e = 0; e < m; e++) {
+            const char *b = &blob[(size_t)(6 * e)];
+            db.branch_ids.push_back((uint16_t)((uint8_t)b[0] << 8 | (uint8_t)b[1]));
+            db.scores.push_back(bef(b + 2));
+        }
+        db.row_offsets.push_back(db.branch_ids.size());
+        rows_seen++;
+    });
     std::string blocks;
     std::vector<P> objs;
-    for (const auto &r : recs) {
-        if (r.is_block) blocks += r.value->s;
-        else objs.push_back(r.value);
-    }
+    reader.contents([&](size_t, rkjs::Record &&r) {
+        if (r.is_block) {
+            blocks += r.value->s;
+            if (blocks.size() >= 4 && db.k == 0) db.k = be32(&blocks[0]);  // (k precedes every object: the keys' range check needs it)
+            return true;
+        }
+        const size_t oi = objs.size();
+        const bool keep = oi == 0 || oi == 2 || oi == 6;
+        if (oi == 0 && r.value && r.value->kind == Node::OBJECT)
+            alphabet_seen = r.value->classname() == "core.DNAStatesShifted" ? 4u : (r.value->classname() == "core.AAStates" ? 20u : 0u);
+        objs.push_back(keep ? r.value : nullptr);
+        return keep;
+    });
     if (blocks.size() < 33 || objs.size() < 7)
         throw std::runtime_error("union: expected 33 bytes of scalars and 7 objects, found " + std::to_string(blocks.size()) + " and " +
                                  std::to_string(objs.size()) + " (a database stored without its hash?)");
-    UnionDb db;
     db.k = be32(&blocks[0]);
     db.omega = bef(&blocks[8]);
     db.thr = bef(&blocks[20]);
@@ -743,38 +792,10 @@ inline UnionDb load_uniondb(const std::string &data) {
     // ---- hash ----
     const P outer = chash->get("hash");
     if (!outer || outer->kind != Node::OBJECT) throw std::runtime_error("union: CustomHash_v4_FastUtil81 without its map");
-    const std::string oname = "it.unimi.dsi.fastutil.objects.Object2ObjectOpenCustomHashMap", rname = "it.unimi.dsi.fastutil.chars.Char2FloatOpenHashMap";
-    const std::vector<P> kv = outer->objects(oname);
     const P osize = outer->get("size");
     const int64_t n_keys = osize ? osize->i : -1;
-    if (n_keys < 0 || kv.size() != (size_t)(2 * n_keys))
-        throw std::runtime_error("union: outer map announces " + std::to_string(n_keys) + " entries, stream holds " + std::to_string(kv.size() / 2));
-    for (int64_t r = 0; r < n_keys; r++) {
-        const P key = kv[(size_t)(2 * r)], row = kv[(size_t)(2 * r + 1)];
-        if (!key || key->kind != Node::ARRAY || !row || row->kind != Node::OBJECT) throw std::runtime_error("union: malformed entry of the outer map");
-        const std::string &raw = key->s;
-        uint64_t code = 0;
-        if (db.alphabet == 4) {
-            if (raw.size() > 8) throw std::runtime_error("union: DNA key longer than 8 bytes");
-            for (size_t b = 0; b < raw.size(); b++) code |= (uint64_t)(uint8_t)raw[b] << (8 * b);  // compressMer bytes: base i at bits 2*(i%4) of byte i/4
-            if (db.k < 32 && (code >> (2 * db.k))) throw std::runtime_error("union: DNA key has bits beyond 2k");
-        } else {
-            if (raw.size() > 12) throw std::runtime_error("union: amino-acid key longer than 12 states");
-            for (size_t b = 0; b < raw.size(); b++) code |= (uint64_t)(uint8_t)raw[b] << (5 * b);
-        }
-        db.key_codes.push_back(code);
-        const P rsize = row->get("size");
-        const int64_t m = rsize ? rsize->i : -1;
-        const std::string blob = row->block(rname);
-        if (m < 0 || blob.size() != (size_t)(6 * m))
-            throw std::runtime_error("union: row announces " + std::to_string(m) + " entries, stream holds " + std::to_string(blob.size()) + " bytes");
-        for (int64_t e = 0; e < m; e++) {
-            const char *b = &blob[(size_t)(6 * e)];
-            db.branch_ids.push_back((uint16_t)((uint8_t)b[0] << 8 | (uint8_t)b[1]));
-            db.scores.push_back(bef(b + 2));
-        }
-        db.row_offsets.push_back(db.branch_ids.size());
-    }
+    if (n_keys < 0 || have_key || rows_seen != (uint64_t)n_keys)
+        throw std::runtime_error("union: outer map announces " + std::to_string(n_keys) + " entries, stream holds " + std::to_string(rows_seen));
     return db;
 }
 

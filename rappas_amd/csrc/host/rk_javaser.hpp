@@ -14,6 +14,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -122,20 +123,41 @@ class Reader {
     // top-level records: block data for primitive writes, objects for writeObject calls
     std::vector<Record> contents() {
         std::vector<Record> out;
+        contents([&](size_t, Record &&r) { out.push_back(std::move(r)); return true; });
+        return out;
+    }
+    // The same, record by record: `take` gets record number i and says whether it keeps it.  A record it does not keep is let go of
+    // at once, with every object that was read for it (a `.union` file's alignment, extended tree and AR tree are of no use to a
+    // placement); a later reference to one of those objects reads as a DROPPED placeholder.
+    void contents(const std::function<bool(size_t, Record &&)> &take) {
+        size_t i = 0;
         while (p_ < n_) {
             const uint8_t tc = d_[p_];
-            if (tc == TC_BLOCKDATA || tc == TC_BLOCKDATALONG) out.push_back({true, blockdata()});
-            else if (tc == TC_RESET) { p_++; handles_.clear(); }
-            else out.push_back({false, content()});
+            if (tc == TC_BLOCKDATA || tc == TC_BLOCKDATALONG) { take(i++, Record{true, blockdata()}); continue; }
+            if (tc == TC_RESET) { p_++; handles_.clear(); continue; }
+            const size_t h0 = handles_.size();
+            if (!take(i++, Record{false, content()})) drop_handles(h0);
         }
-        return out;
+    }
+    // Objects a class's writeObject wrote behind its fields (its "annotations") are handed to `sink` one by one instead of being kept
+    // with the object -- the entries of a fastutil map with 10^7 rows, turned into CSR rows as they are read -- and let go of at once.
+    void stream_annotations_of(const std::string &class_name, std::function<void(const P &)> sink) {
+        sink_class_ = class_name;
+        sink_ = std::move(sink);
     }
 
   private:
     const uint8_t *d_;
     size_t n_, p_ = 0;
-    struct Handle { P node; std::shared_ptr<ClassDesc> desc; };
+    struct Handle { P node; std::shared_ptr<ClassDesc> desc; bool dropped = false; };
     std::vector<Handle> handles_;
+    std::string sink_class_;
+    std::function<void(const P &)> sink_;
+    // objects read since handle h0 are let go of (class descriptors stay: later objects of the same classes refer to them)
+    void drop_handles(size_t h0) {
+        for (size_t h = h0; h < handles_.size(); h++)
+            if (!handles_[h].desc) { handles_[h].node.reset(); handles_[h].dropped = true; }
+    }
     // Nesting of content() / classdesc() calls.  ObjectOutputStream itself recurses once per nested object and a JVM's default
     // stack gives out after a few thousand levels, so no stream a JVM wrote comes near this; a crafted one stops here, not in a
     // stack overflow (each level costs three or four frames of this reader).
@@ -207,6 +229,12 @@ class Reader {
             const int64_t h = (int64_t)i4() - BASE_WIRE_HANDLE;
             if (h < 0 || h >= (int64_t)handles_.size()) throw Error("back reference to unknown handle " + std::to_string(h), at);
             const Handle &hd = handles_[(size_t)h];
+            if (hd.dropped) {  // an object of a record (or a map entry) the caller let go of: nothing that is kept may need it
+                auto d = std::make_shared<Node>(Node::PRIM);
+                d->ptype = 'X';
+                d->s = "<dropped>";
+                return d;
+            }
             if (hd.desc) {  // a class descriptor used as a value
                 auto c = std::make_shared<Node>(Node::CLASSDESC);
                 c->desc = hd.desc;
@@ -323,7 +351,7 @@ class Reader {
         return d;
     }
 
-    std::vector<P> annotations() {
+    std::vector<P> annotations(bool to_sink = false) {
         std::vector<P> out;
         while (true) {
             if (p_ >= n_) throw Error("truncated stream inside an annotation", p_);
@@ -331,7 +359,12 @@ class Reader {
             if (tc == TC_ENDBLOCKDATA) { p_++; return out; }
             if (tc == TC_BLOCKDATA || tc == TC_BLOCKDATALONG) out.push_back(blockdata());
             else if (tc == TC_RESET) p_++;
-            else out.push_back(content());
+            else if (to_sink) {
+                const size_t h0 = handles_.size();
+                const P x = content();
+                sink_(x);
+                drop_handles(h0);
+            } else out.push_back(content());
         }
     }
 
@@ -341,7 +374,7 @@ class Reader {
                 std::map<std::string, P> vals;
                 for (const auto &f : d->fields) vals[f.name] = is_prim(f.type) ? prim(f.type) : content();
                 obj.fields.emplace_back(d->name, std::move(vals));
-                if (d->flags & SC_WRITE_METHOD) obj.annotations.emplace_back(d->name, annotations());
+                if (d->flags & SC_WRITE_METHOD) obj.annotations.emplace_back(d->name, annotations(sink_ && d->name == sink_class_));
             } else if (d->flags & SC_EXTERNALIZABLE) {
                 if (!(d->flags & SC_BLOCK_DATA)) throw Error(d->name + ": Externalizable data of stream protocol 1 cannot be delimited", p_);
                 obj.annotations.emplace_back(d->name, annotations());

@@ -9,6 +9,8 @@
 #include <iostream>
 #include <sstream>
 
+#include <sys/resource.h>
+
 #include "../../../include/rappas_place.h"
 #include "rk_hostio.hpp"
 #include "rk_fastio.hpp"
@@ -196,6 +198,17 @@ int main(int argc, char **argv) {
                 std::cout << recs.size() << " reads, " << dd.first_rec.size() << " unique, " << text.size() << " bytes\n"
                           << "parse " << recs.size() / (t1 - t0) / 1e6 << " Mreads/s (" << text.size() / (t1 - t0) / 1e6 << " MB/s)\n"
                           << "dedup " << recs.size() / (t2 - t1) / 1e6 << " Mreads/s\n";
+                return 0;
+            } else if (a == "--uniondb-stats") {  // load a `.union` file and say what it cost: rows, entries, peak resident memory (CPU tests)
+                const std::string path = val();
+                size_t rows, entries, nodes;
+                {
+                    const rkh::UnionDb db = rkh::load_uniondb(slurp(path));
+                    rows = db.key_codes.size(); entries = db.scores.size(); nodes = db.tree.nodes.size();
+                }
+                struct rusage ru;
+                getrusage(RUSAGE_SELF, &ru);
+                std::cout << rows << " " << entries << " " << nodes << " " << ru.ru_maxrss << "\n";  // (ru_maxrss: kilobytes on Linux)
                 return 0;
             } else if (a == "--load-uniondb") {  // what load_uniondb makes of a `.union` stream (compared with the Python twin)
                 const rkh::UnionDb db = rkh::load_uniondb(slurp(val()));

@@ -226,7 +226,8 @@ def phylo_tree(nodes_spec, rooted):
 
 def union_stream(alphabet, k, omega, thr, thr_log10, tree_obj, rows, convert_uo=False, calibration=float("-inf"), only_fakes=True,
                  long_blocks=False):
-    """rows: list of (key bytes, [(node id, float), ...])"""
+    """rows: list of (key bytes, [(node id, float), ...]); a row may also be its entries already packed big-endian (bytes of 6 per
+    entry: u16 node id, f32 value), which is how the large streams of the memory test are written"""
     w = Writer()
     w.block(struct.pack(">iififff", k, k, omega, 1, 1.4e-45, thr, thr_log10))
     if alphabet == 4:
@@ -246,8 +247,9 @@ def union_stream(alphabet, k, omega, thr, thr_log10, tree_obj, rows, convert_uo=
     w.block(struct.pack(">f?", calibration, only_fakes))
     kv = []
     for key, row in rows:
-        blob = b"".join(struct.pack(">Hf", n, v) for n, v in row)
-        r = Obj(C2F, {C2F.name: {"f": 0.75, "size": len(row)}, C2F_FUNC.name: {"defRetValue": 0.0}}, {C2F.name: [blob] if blob else []})
+        blob = bytes(row) if isinstance(row, (bytes, bytearray)) else b"".join(struct.pack(">Hf", n, v) for n, v in row)
+        size = len(blob) // 6
+        r = Obj(C2F, {C2F.name: {"f": 0.75, "size": size}, C2F_FUNC.name: {"defRetValue": 0.0}}, {C2F.name: [blob] if blob else []})
         kv += [Arr(BYTE_ARRAY, [b - 256 if b > 127 else b for b in key]), r]
     outer = Obj(O2O, {O2O.name: {"f": 0.8, "size": len(rows), "strategy": Obj(HASHSTRATEGY)}, O2O_FUNC.name: {"defRetValue": None}}, {O2O.name: kv})
     w.obj(Obj(CUSTOMHASH, {CUSTOMHASH.name: dict(maxCapacitySize=alphabet ** k, nodeType=2, hash=outer, preparedNovelMap=None)}))

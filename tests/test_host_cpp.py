@@ -247,3 +247,34 @@ def test_database_image_from_the_tool_without_a_gpu(rk_place, tmp_path):
     info, blob = ra.db_image_info(str(img))
     assert (info.k, info.n_branches, info.n_keys, info.n_entries) == (6, 21, db.n_keys, db.n_entries)
     assert blob.startswith(b"RKTREE 1 21 0\n") and blob.count(b"\n") == 22
+
+
+def test_union_reader_streams_a_ten_million_entry_database(rk_place, tmp_path):
+    """a `.union` stream of 10^7 row entries in 3 x 10^5 rows (tests/javaser_writer.py; alignment, extended tree, AR tree and node
+    mapping in front of the hash as SessionNext_v2.storeHash writes them): the native reader turns the rows into CSR as it reads them
+    and lets go of the objects a placement has no use for -- peak resident memory stays a small multiple of the file (the round-3
+    reader held a node graph per row: gigabytes here, tens of GB for a 10^7-ROW session)"""
+    from tests import javaser_writer as JW
+    n_rows, per_row, k = 300_000, 33, 10
+    rng = np.random.default_rng(3)
+    codes = rng.choice(4 ** k, size=n_rows, replace=False).astype(np.uint64)
+    ent = np.zeros(n_rows * per_row, dtype=np.dtype([("b", ">u2"), ("v", ">f4")]))
+    ent["b"] = (np.arange(n_rows * per_row) % per_row) + 1 + np.repeat(rng.integers(0, 900, n_rows), per_row)
+    ent["v"] = -rng.random(n_rows * per_row, dtype=np.float32) * 4
+    raw = ent.tobytes()
+    tree = hostio.parse_newick(synth.make_newick(999, seed=6))
+    spec = [(n.id, n.label, float(n.bl), n.jplace_edge, n.parent.id if n.parent is not None else None) for n in tree.nodes]
+    rows = [(int(c).to_bytes(3, "little"), raw[i * per_row * 6:(i + 1) * per_row * 6]) for i, c in enumerate(codes.tolist())]
+    blob = JW.union_stream(4, k, 1.5, 1e-5, -5.0, JW.phylo_tree(spec, tree.rooted), rows)
+    path = tmp_path / "big.union"
+    path.write_bytes(blob)
+    size = len(blob)
+    del rows, blob, raw, ent
+    # (ru_maxrss survives exec: a process starts with its parent's resident size as its "peak".  The tool is therefore started by a
+    #  small interpreter of its own, not by this one, which holds the stream it has just written)
+    import sys
+    out = run(sys.executable, "-c", "import subprocess, sys; sys.exit(subprocess.run(sys.argv[1:]).returncode)", rk_place, "--uniondb-stats", str(path)).split()
+    assert (int(out[0]), int(out[1]), int(out[2])) == (n_rows, n_rows * per_row, 999)
+    rss = int(out[3]) * 1024
+    # the file once (read whole), its CSR form (8 + 8 bytes a row, 6 an entry; vectors grow by doubling) and little else
+    assert size > 60e6 and rss < 5 * size and rss < 400e6, (size, rss)
