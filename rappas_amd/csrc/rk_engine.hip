@@ -1606,7 +1606,7 @@ struct WgGeometry {
 // The score vector of one read (4 bytes per branch) is shared by the NW waves of a workgroup.  While it fits, one pass:
 // two workgroups of 8 waves per CU when two vectors fit (C5: 19 999 branches = 80 KB), else one of 16 waves.  Trees beyond one
 // CU's LDS (about 39 000 branches; the reference's limit is the 16-bit id: 65 534) take 2 or 4 branch-range passes per read.
-static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
+static int choose_wg_geometry(const rk_db *db, WgGeometry &g, uint32_t keep_at_most = 16) {
     const uint32_t nb = db->info.n_branches;
     uint32_t min_pass = 1;
     if (const char *e = rk_knob("RK_WG_PASSES")) min_pass = (uint32_t)atoi(e);  // developer / test knob: force 2 or 4 passes on a tree that fits in one
@@ -1624,10 +1624,11 @@ static int choose_wg_geometry(const rk_db *db, WgGeometry &g) {
             if (P > 1 && wgs == 2) continue;  // (a tree that needs passes with 8 waves fits whole with 16)
             const uint32_t nw = wgs == 2 ? 8 : 16;
             const size_t budget = db->lds_per_cu / wgs;
-            // P == 1: the wave winners of the level-1 select go to the (then idle) hit list; P > 1: a region of their own
-            const size_t cand = P > 1 ? (size_t)(P * nw * 16 + 16 + 2) * 8 : 0;
+            // P == 1: the wave winners of the level-1 select go to the hit list (free once every wave has its slices of the batch's rows);
+            // P > 1: a region of their own.  (C5's two workgroups of 80 000-byte score vectors per CU leave ~1.9 KB)
+            const size_t cand = P > 1 ? (size_t)(P * nw * keep_at_most + 16 + 2) * 8 : 0;
             const size_t extra = 256 + cand;  // per-wave hit counters
-            const size_t min_list = P > 1 ? 66 : (size_t)(nw * 16 + 16 + 2);
+            const size_t min_list = P > 1 ? 66 : std::max<size_t>(66, (size_t)nw * keep_at_most + 18);
             if (budget < s_bytes + extra + min_list * 8) continue;
             size_t cap = (budget - s_bytes - extra) / 8;
             if (cap > 512) cap = 512;
@@ -1754,7 +1755,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     char buf[200];
     if (db->indexed && db->lanes_per_read == 0) {
         WgGeometry wg;
-        if (choose_wg_geometry(db, wg) != RK_OK) return "";
+        if (choose_wg_geometry(db, wg, 7) != RK_OK) return "";
         snprintf(buf, sizeof(buf), "place_wg_kernel<BITS=%u,%s,%s,U=%d> waves/WG=%u lds/WG=%zuB rows/batch=%u WGs/CU=%u passes=%u",
                  db->info.bits_per_symbol, db->info.table_mode == RK_TABLE_HASH ? "HASH" : "DIRECT8",
                  db->info.rows_bytes < ROWS_FIT32_LIMIT ? "OFF32" : "OFF64", RK_WG_RING, wg.nw, wg.lds, wg.list_cap, wg.wgs_per_cu, wg.n_pass);
@@ -1830,7 +1831,7 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
     const bool use_win = !use_wg && use_windowed(db, p->keep_at_most, words_per_read);
     Geometry g{};
     WgGeometry wg{};
-    rc = use_wg ? choose_wg_geometry(db, wg) : (use_win ? RK_OK : choose_geometry(db, p->keep_at_most, g));  // (the windowed launch has its own plan)
+    rc = use_wg ? choose_wg_geometry(db, wg, p->keep_at_most) : (use_win ? RK_OK : choose_geometry(db, p->keep_at_most, g));  // (the windowed launch has its own plan)
     if (rc) return rc;
     HIP_TRY(hipSetDevice(db->info.device));
     hipStream_t s = (hipStream_t)stream;

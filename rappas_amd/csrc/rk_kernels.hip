@@ -2830,15 +2830,22 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_SLOTS = 4;  // rows per lane in the slice table of a wave: a probe batch holds <= 64 * WG_SLOTS rows
 
-template <bool WIDE, int U>
-__device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, u32 base, const u64 *list, int cnt, u32 lane, u32 q_lo, u32 q_hi,
-                                                const unsigned char *rows, float QT, float T) {
+// this wave's slices of the rows of a probe batch (phase A of the accumulate: the hit list is read here and nowhere later)
+template <bool WIDE>
+struct WaveSlices {
     typedef typename OffsetT<WIDE>::type off_t;
-    // ---- phase A: this wave's slice [start, start + n) of every row of the batch (row h lives in lane h%64, slot h/64)
-    // rows of an indexed image: [64-byte index line][u16 branch[len]][f32 score[len]], len a multiple of 32
     off_t start[WG_SLOTS];   // byte offset of the slice's first branch id
     off_t sstart[WG_SLOTS];  // byte offset of the slice's first score
     u32 nn[WG_SLOTS];
+};
+template <bool WIDE>
+__device__ __forceinline__ void wave_slices(WaveSlices<WIDE> &ws, const u64 *list, int cnt, u32 lane, u32 q_lo, u32 q_hi, const unsigned char *rows) {
+    typedef typename OffsetT<WIDE>::type off_t;
+    // the slice [start, start + n) of every row of the batch (row h lives in lane h%64, slot h/64)
+    // rows of an indexed image: [64-byte index line][u16 branch[len]][f32 score[len]], len a multiple of 32
+    off_t (&start)[WG_SLOTS] = ws.start;
+    off_t (&sstart)[WG_SLOTS] = ws.sstart;
+    u32 (&nn)[WG_SLOTS] = ws.nn;
 #pragma unroll
     for (int sl = 0; sl < WG_SLOTS; sl++) {
         const int h = (int)lane + 64 * sl;
@@ -2855,6 +2862,14 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, u32 base, const 
         start[sl] = off + (off_t)lo * 2;
         sstart[sl] = off + (off_t)lenp * 2 + (off_t)lo * 4;
     }
+}
+
+template <bool WIDE, int U>
+__device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, u32 base, const WaveSlices<WIDE> &ws, u32 lane, const unsigned char *rows, float QT, float T) {
+    typedef typename OffsetT<WIDE>::type off_t;
+    const off_t (&start)[WG_SLOTS] = ws.start;
+    const off_t (&sstart)[WG_SLOTS] = ws.sstart;
+    const u32 (&nn)[WG_SLOTS] = ws.nn;
     u64 mk[WG_SLOTS];
 #pragma unroll
     for (int sl = 0; sl < WG_SLOTS; sl++) mk[sl] = __ballot(nn[sl] > 0);
@@ -2917,25 +2932,41 @@ __device__ __forceinline__ void wave_accumulate(u32 *S, u32 nb, u32 base, const 
     }
 }
 
-// exact top-K of the quads [q0, q1) of S by K rounds of "largest key below the previous winner" (rare fallback)
-__device__ __forceinline__ int select_rounds64(const u32 *S, u32 nb, u32 base, u32 q0, u32 q1, u32 lane, int K, u64 &win_key) {
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {  // wave-uniform maximum of a 64-bit key: its halves in turn
+    const u32 hi = wave_max_u32((u32)(v >> 32));
+    const u32 lo = wave_max_u32((u32)(v >> 32) == hi ? (u32)v : 0u);
+    return ((u64)hi << 32) | lo;
+}
+// the slots [s0, s1) of S as quads for a scan: a quad's words outside the range read as UNTOUCHED
+__device__ __forceinline__ uint4 quad_in_range(const uint4 *S4, u32 q, u32 s0, u32 s1) {
+    uint4 v4 = S4[q];
+    const u32 i = 4 * q;
+    if (i < s0 || i >= s1) v4.x = S_UNTOUCHED;
+    if (i + 1 < s0 || i + 1 >= s1) v4.y = S_UNTOUCHED;
+    if (i + 2 < s0 || i + 2 >= s1) v4.z = S_UNTOUCHED;
+    if (i + 3 < s0 || i + 3 >= s1) v4.w = S_UNTOUCHED;
+    return v4;
+}
+// exact top-K of the slots [s0, s1) of S by K rounds of "largest key below the previous winner" (fallback of the stream heads)
+__device__ __forceinline__ int select_rounds64(const u32 *S, u32 base, u32 s0, u32 s1, u32 lane, int K, u64 &win_key) {
     const uint4 *S4 = (const uint4 *)S;
+    const u32 q0 = s0 / 4, q1 = (s1 + 3) / 4;
     u64 prev = ~0ull;
     int num = 0;
     win_key = 0;
     for (int r = 0; r < K; r++) {
         u64 best = 0;
         for (u32 q = q0 + lane; q < q1; q += 64) {
-            const uint4 v4 = S4[q];
+            const uint4 v4 = quad_in_range(S4, q, s0, s1);
             const u32 raw[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const u32 i = 4 * q + e;
-                const u64 key = (raw[e] != S_UNTOUCHED && i < nb) ? make_key(raw[e], i + base) : 0ull;
+                const u64 key = raw[e] != S_UNTOUCHED ? make_key(raw[e], i + base) : 0ull;
                 best = (key < prev && key > best) ? key : best;
             }
         }
-        const u64 mx = group_max<64>(best);
+        const u64 mx = wave_max_u64(best);
         if (mx == 0) break;
         if ((int)lane == r) win_key = mx;
         prev = mx;
@@ -2951,7 +2982,8 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
     u32 *S = lds;
     u64 *list = (u64 *)(lds + a.s_stride);
     u32 *wcnt = (u32 *)(list + a.list_cap);  // [NW] hits per wave of the current probe batch
-    // wave winners of every pass (level-2 select input): one pass -> the hit list, idle by then; several -> a region of their own
+    // wave winners of every pass (level-2 select input): one pass -> the hit list, free once every wave has its slices; several -> a
+    // region of their own
     u64 *cand = a.n_pass == 1 ? list : (u64 *)(wcnt + 64);
     const u32 nb = a.db.n_branches, k = a.db.k;
     const float T = a.db.T;
@@ -2969,6 +3001,9 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     for (u32 i = tid; i < a.s_stride; i += blockDim.x) S[i] = S_UNTOUCHED;
     __syncthreads();
+#ifdef RK_STAMPS
+    unsigned long long st_[16] = {0}, t_ = rk_now();
+#endif
 
     for (u64 r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
         u32 R = a.lens ? a.lens[r] : a.fixed_len;
@@ -2988,10 +3023,11 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
             const u32 base = (u32)(((u64)p_lo * nb) / 32);          // first branch of the pass
             const u32 win = (u32)(((u64)p_hi * nb) / 32) - base;    // branches of the pass (<= s_stride - 1)
             const u32 q_lo = p_lo + wave * span / NW, q_hi = p_lo + (wave + 1) * span / NW;  // index-line ranges of this wave
-            const u32 n4 = (win + 3) / 4, n4_full = win / 4;
-            const u32 qpw = (n4 + NW - 1) / NW;                       // quads of S this wave scans in the select phase
-            const u32 sq0 = wave * qpw < n4 ? wave * qpw : n4;
-            const u32 sq1 = sq0 + qpw < n4 ? sq0 + qpw : n4;
+            // the slots of S this wave owns: the branches of its index-line ranges.  Nobody else touches them, so the wave goes from its
+            // accumulate straight into the select of its own segment (round 4: a barrier stood between the two and the select cut S
+            // into equal parts instead -- a row of neighbouring branches keeps one or two of the waves busy, the others waited for them
+            // and then scanned while those waited in turn)
+            const u32 s0 = (u32)(((u64)q_lo * nb) / 32) - base, s1 = (u32)(((u64)q_hi * nb) / 32) - base;
             for (u32 pos0 = 0; pos0 < Q; pos0 += batch) {
                 // ---- probe: thread <-> k-mer position; hits compacted in position order across the workgroup ----
                 const u32 j = pos0 + tid;
@@ -3004,6 +3040,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                     desc = lookup_desc<BITS, TM>(a.db, extract_code<BITS>(rec, a.words_per_read, j, k));
                 }
                 const bool hit = ((u32)desc & DESC_LEN_MASK) != 0;
+                RK_STAMP(0);  // probe (record words, table)
                 const u64 bal = __ballot(hit);
                 if (lane == 0) wcnt[wave] = (u32)__builtin_popcountll(bal);
                 __syncthreads();
@@ -3015,48 +3052,133 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                 }
                 if (hit) list[hbase + __builtin_popcountll(bal & ((1ull << lane) - 1))] = desc;
                 __syncthreads();
+                RK_STAMP(1);  // compaction of the hits (two barriers)
                 // ---- accumulate: every wave applies its branch range of every row, rows in k-mer order ----
-                if (cnt > 0 && q_hi > q_lo) wave_accumulate<WIDE, U>(S, win, base, list, (int)cnt, lane, q_lo, q_hi, a.db.rows, QT, T);
+                // every wave's slices of the batch's rows first (the only reads of the hit list), then a barrier: from here on the list
+                // is free -- a wave that is through with its range leaves its winners there while others still stream
+                const bool work = cnt > 0 && q_hi > q_lo;
+                WaveSlices<WIDE> ws;
+                if (work) wave_slices<WIDE>(ws, list, (int)cnt, lane, q_lo, q_hi, a.db.rows);
                 __syncthreads();
+                RK_STAMP(3);  // slices of the batch's rows (index lines)
+                if (work) wave_accumulate<WIDE, U>(S, win, base, ws, lane, a.db.rows, QT, T);
+                RK_STAMP(2);  // accumulate (this wave's branch range)
+                if (pos0 + batch < Q) __syncthreads();  // (the list is rewritten by the next batch's probe)
             }
 
             // ---- select, level 1: every wave ranks its segment of S (stream heads as in select_topk, K rounds of wave max) ----
             Heads4 hd;
             heads_clear(hd);
-            for (u32 q = sq0 + lane; q < sq1; q += 64) {
-                uint4 v4 = S4[q];
-                if (q >= n4_full) {  // the partial last quad of the window
-                    const u32 i = 4 * q;
-                    if (i >= win) v4.x = S_UNTOUCHED;
-                    if (i + 1 >= win) v4.y = S_UNTOUCHED;
-                    if (i + 2 >= win) v4.z = S_UNTOUCHED;
-                    if (i + 3 >= win) v4.w = S_UNTOUCHED;
-                }
-                heads_feed_quad(hd, v4, q);
-            }
+            const u32 sq0 = s0 / 4, sq1 = (s1 + 3) / 4;
+            for (u32 q = sq0 + lane; q < sq1; q += 64) heads_feed_quad(hd, quad_in_range(S4, q, s0, s1), q);
             u32 win_o, win_i;
             bool doubt;
             int num = heads_rounds_raw<64>(hd, K, lane, 0u, win_o, win_i, doubt);
             u64 wkey = ((int)lane < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i + base))) : 0ull;
-            if (__any(doubt)) num = select_rounds64(S, win, base, sq0, sq1, lane, K, wkey);
-            for (u32 q = sq0 + lane; q < sq1; q += 64) S4w[q] = reset4;
+            if (__any(doubt)) {
+#ifdef RK_STAMPS
+                st_[12] += 1;
+#endif
+                // A stream dropped an entry that could be among the K best.  The K-th key the heads did find is a lower bound of the
+                // true K-th (it is a real entry), so every true winner is at or above it: one more pass over the segment keeps those
+                // entries -- two a lane, in registers -- and K rounds of wave maxima rank them exactly.  A lane with more than two (or
+                // a segment with fewer than K entries in the heads) takes the K passes of select_rounds64.
+                u64 tau = 0ull;
+                if (num == K) {
+                    const u32 th = (u32)__builtin_amdgcn_readlane((int)(u32)(wkey >> 32), K - 1), tl = (u32)__builtin_amdgcn_readlane((int)(u32)wkey, K - 1);
+                    tau = ((u64)th << 32) | tl;
+                }
+                u64 c0 = 0ull, c1 = 0ull;
+                bool over = num != K;
+                if (!over) {
+                    for (u32 q = sq0 + lane; q < sq1; q += 64) {
+                        const uint4 v4 = quad_in_range(S4, q, s0, s1);
+                        const u32 raw[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const u64 key = raw[e] != S_UNTOUCHED ? make_key(raw[e], 4 * q + e + base) : 0ull;
+                            const bool is = key >= tau && key != 0ull;
+                            over = over || (is && c1 != 0ull);
+                            c1 = (is && c0 != 0ull && c1 == 0ull) ? key : c1;
+                            c0 = (is && c0 == 0ull) ? key : c0;
+                        }
+                    }
+                }
+                if (__any(over)) {
+#ifdef RK_STAMPS
+                    st_[13] += 1;
+#endif
+                    num = select_rounds64(S, base, s0, s1, lane, K, wkey);
+                } else {
+                    num = 0;
+                    wkey = 0ull;
+                    for (int rr = 0; rr < K; rr++) {
+                        const u64 top = wave_max_u64(c0 > c1 ? c0 : c1);
+                        if (top == 0ull) break;
+                        if ((int)lane == rr) wkey = top;
+                        num++;
+                        c0 = c0 == top ? 0ull : c0;
+                        c1 = c1 == top ? 0ull : c1;
+                    }
+                }
+            }
             if ((int)lane < K) cand[(pass * NW + wave) * K + lane] = ((int)lane < num) ? wkey : 0ull;
+            // reset: whole quads inside the range, single words in the two quads it may share with its neighbours' ranges
+            for (u32 q = sq0 + lane; q < sq1; q += 64) {
+                if (4 * q >= s0 && 4 * q + 4 <= s1) S4w[q] = reset4;
+                else
+                    for (u32 e = 0; e < 4; e++)
+                        if (4 * q + e >= s0 && 4 * q + e < s1) S[4 * q + e] = S_UNTOUCHED;
+            }
+            RK_STAMP(4);  // level-1 select of this wave's segment
             __syncthreads();
+            RK_STAMP(5);  // barrier behind it
         }
         // ---- select, level 2 (wave 0): exact top-K of the n_pass*NW*K wave winners, then weights and output rows ----
         if (wave == 0) {
+            // K rounds of "largest key left" over the candidates, a few per lane, by wave-wide maxima of the two key halves (DPP row
+            // steps + four SGPR reads; round 4 -- ranking 56 ... 112 candidates against each other by 63 lane rotations or c^2 / 64 LDS
+            // reads left the other waves of the workgroup waiting for ~4 000 cycles a read); keys are unique, 0 = no candidate
             const int c = (int)(P * NW) * K;
-            u64 *win = cand + ((c + 1) & ~1);
-            if ((int)lane < K) win[lane] = 0ull;
-            wave_lds_fence();
-            rank_candidates<64>(cand, c, win, K, lane);
-            const u64 win_key = ((int)lane < K) ? win[lane] : 0ull;
-            const int numBest = __builtin_popcountll(__ballot(win_key != 0));
+            u64 win_key = 0ull;
+            int numBest = 0;
+            if (c <= 256) {  // (one pass: <= 16 waves x 16 winners)
+                u64 mine[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) mine[q] = ((int)lane + 64 * q < c) ? cand[lane + 64 * q] : 0ull;
+                for (int rr = 0; rr < K; rr++) {
+                    u64 best = mine[0] > mine[1] ? mine[0] : mine[1];
+                    const u64 b2 = mine[2] > mine[3] ? mine[2] : mine[3];
+                    const u64 top = wave_max_u64(best > b2 ? best : b2);
+                    if (top == 0ull) break;
+                    if ((int)lane == rr) win_key = top;
+                    numBest++;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) mine[q] = mine[q] == top ? 0ull : mine[q];
+                }
+            } else {  // several branch-range passes (trees beyond one CU's LDS): the counting rank
+                u64 *win = cand + ((c + 1) & ~1);
+                if ((int)lane < K) win[lane] = 0ull;
+                wave_lds_fence();
+                rank_candidates<64>(cand, c, win, K, lane);
+                win_key = ((int)lane < K) ? win[lane] : 0ull;
+                numBest = __builtin_popcountll(__ballot(win_key != 0));
+            }
             const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
-            if (!deferred) weigh_and_store<64>(a, r, lane, numBest, win_key, flags);
+            // (keep_at_most <= 16: the winners sit in the wave's first 16-lane row -- the DPP form of the weighing)
+            if (!deferred) weigh_and_store<16>(a, r, lane, numBest, win_key, flags);
         }
+        RK_STAMP(6);  // level-2 select + weights + store (wave 0)
         __syncthreads();
+        RK_STAMP(7);  // the other waves waiting for it
+#ifdef RK_STAMPS
+        st_[11] += 1;
+#endif
     }
+#ifdef RK_STAMPS
+    if (lane == 0 && blockIdx.x < 512 && (wave == 0 || wave == NW - 1))
+        for (int i = 0; i < 16; i++) rk_stamp_buf[((u64)blockIdx.x * 2 + (wave ? 1 : 0)) * 16 + i] = st_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
