@@ -94,6 +94,52 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- wave ballots cut into lane groups, and counts below a lane, WITHOUT 64-bit shifts by a variable count: on gfx950 such a shift
+//      reads its count from v0 when hipcc happens to put it into the kernel's last VGPR; the build refuses that code
+//      (tools/check_isa.py), these forms do not produce it in the first place ----
+// the G bits of a wave ballot that belong to lane group gi (G consecutive lanes)
+template <int G>
+__device__ __forceinline__ u64 group_bits(u64 bal, u32 gi) {
+    if (G == 64) return bal;
+    u32 lo = (u32)bal, hi = (u32)(bal >> 32);
+    asm("" : "+v"(lo), "+v"(hi));  // (two separate words from here on: left to itself the optimiser puts the choice of a half back together as a 64-bit shift by gi * G)
+    if (G == 32) return gi ? hi : lo;
+    constexpr u32 PER = 32 / (G < 32 ? G : 32);  // groups per 32-bit half
+    const u32 half = gi >= PER ? hi : lo;
+    return (half >> ((gi % PER) * (u32)G)) & ((1u << (G < 32 ? G : 31)) - 1u);
+}
+// popcount(m & ((1 << li) - 1)) for a group's bits m (li = lane in group; G == 64: li is the lane itself)
+template <int G>
+__device__ __forceinline__ int count_below(u64 m, u32 li) {
+    if (G <= 32) return __builtin_popcount((u32)m & ((1u << li) - 1u));
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+// the n lowest bits of a 64-bit word set, n in 0 .. 64 (a mask of windows / of lanes below a position), from two 32-bit words
+__device__ __forceinline__ u64 bits_below(u32 n) {
+    u32 lo = n >= 32u ? 0xFFFFFFFFu : ((1u << (n & 31u)) - 1u);
+    u32 hi = n <= 32u ? 0u : (n >= 64u ? 0xFFFFFFFFu : ((1u << ((n - 32u) & 31u)) - 1u));
+    asm("" : "+v"(lo), "+v"(hi));  // (kept apart: see group_bits)
+    return ((u64)hi << 32) | lo;
+}
+// a small value (a state: < 32) moved to bit position sh < 64 of a 64-bit code
+__device__ __forceinline__ u64 place_bits(u32 v, u32 sh) {
+    // bits of v that stay in the low word / spill into the high word, by 32-bit shifts (v < 2^5: at most 4 bits spill)
+    u32 lo = sh < 32u ? v << (sh & 31u) : 0u;
+    u32 hi = sh >= 32u ? v << ((sh - 32u) & 31u) : ((sh & 31u) ? v >> ((32u - sh) & 31u) : 0u);
+    asm("" : "+v"(lo), "+v"(hi));  // (kept apart: see group_bits)
+    return ((u64)hi << 32) | lo;
+}
+// bit `lane` of a wave mask
+__device__ __forceinline__ bool lane_bit(u64 m, u32 lane) {
+    u32 lo = (u32)m, hi = (u32)(m >> 32);
+    asm("" : "+v"(lo), "+v"(hi));
+    return (((lane & 32u) ? hi : lo) >> (lane & 31u)) & 1u;
+}
+// bits [sh, sh + 64) of the 96-bit little-endian string w2:w1:w0 (sh < 32): two 32-bit funnel shifts (v_alignbit_b32)
+__device__ __forceinline__ u64 funnel96(u32 w0, u32 w1, u32 w2, u32 sh) {
+    return ((u64)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+}
+
 // entry e of the row a descriptor points at, for either row layout (8-byte {branch, score} pairs, or -- large-tree
 // images -- a u16 branch array followed by an f32 score array)
 __device__ __forceinline__ void load_entry(const DbView &db, u64 desc, u32 e, u32 &br, float &sc) {
@@ -122,15 +168,14 @@ __device__ __forceinline__ u64 extract_code(const u32 *rec, u32 words, u32 j, u3
     const u32 i1 = wi + 1 < words ? wi + 1 : last;
     u32 w1 = rec[i1];
     w1 = wi + 1 < words ? w1 : 0u;
-    const u64 lo = ((u64)w1 << 32) | w0;
-    u64 code = lo >> sh;
     const u32 nbits = k * BITS;
+    u32 w2 = 0u;
     if (BITS == 5 || nbits + 31 > 64) {  // AA with k >= 7 and DNA with k >= 17 can need a third word (uniform test)
         const u32 i2 = wi + 2 < words ? wi + 2 : last;
-        u32 w2 = rec[i2];
+        w2 = rec[i2];
         w2 = (wi + 2 < words && nbits + sh > 64) ? w2 : 0u;
-        code |= sh ? ((u64)w2 << (64 - sh)) : 0ull;
     }
+    const u64 code = funnel96(w0, w1, w2, sh);  // (32-bit funnel shifts: no 64-bit shift by a per-lane count)
     return nbits >= 64 ? code : (code & ((1ull << nbits) - 1));
 }
 
@@ -568,7 +613,6 @@ template <int G>
 __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, int K, u64 *list, int cap, u64 &win_key RK_STAMP_PARAMS) {
     // slot layout: S[0] is the scratch word (the caller has set it to UNTOUCHED), branch x is S[x + 1], ns = n_branches + 1
     const u32 nb = ns;
-    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     u64 *win = list + (cap - 16);
     const int capc = cap - 16;
     const uint4 *S4 = (const uint4 *)S;
@@ -608,11 +652,11 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, 
             key[e] = (raw[e] != S_UNTOUCHED && i + e < nb) ? make_key(raw[e], i + e - 1u) : 0ull;
             any = any || (key[e] != 0 && key[e] >= tau);
         }
-        if (((__ballot(any) >> (gi * G)) & gmask) == 0) continue;  // group-uniform: no candidate in these 4G entries
+        if (group_bits<G>(__ballot(any), gi) == 0) continue;  // group-uniform: no candidate in these 4G entries
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const bool cand = key[e] != 0 && key[e] >= tau;
-            const u64 sub = (__ballot(cand) >> (gi * G)) & gmask;
+            const u64 sub = group_bits<G>(__ballot(cand), gi);
             if (sub == 0) continue;
             if (c + G > capc) {  // prune: keep the exact top-K, raise tau
                 wave_lds_fence();
@@ -623,8 +667,8 @@ __device__ __forceinline__ int select_topk_scan(u32 *S, u32 ns, u32 li, u32 gi, 
                 c = kept;
             }
             const bool still = cand && key[e] >= tau;
-            const u64 sub2 = (__ballot(still) >> (gi * G)) & gmask;
-            if (still) list[c + __builtin_popcountll(sub2 & ((1ull << li) - 1))] = key[e];
+            const u64 sub2 = group_bits<G>(__ballot(still), gi);
+            if (still) list[c + count_below<G>(sub2, li)] = key[e];
             c += __builtin_popcountll(sub2);
         }
     }
@@ -750,7 +794,6 @@ __device__ __forceinline__ void heads_scan(u32 *S, u32 ns, u32 li, u32 slot_base
 template <int G, bool FULLQ = false>  // FULLQ: a head's q is the slot itself (streams fed in any order), not its quad
 __device__ __forceinline__ int heads_rounds_raw(const Heads4 &h, int K, u32 li, u32 gi, u32 &win_o, u32 &win_i, bool &doubt, u32 *kth_o = nullptr) {
     constexpr u32 ORD_NEG_INF = 0x007FFFFFu;  // ord_f32(-inf)
-    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     u32 o0[4], o1[4], n0[4], n1[4];  // n = ~slot: the smaller slot wins a max
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -782,7 +825,7 @@ __device__ __forceinline__ int heads_rounds_raw(const Heads4 &h, int K, u32 li, 
     }
     const u32 od = max(max(ord_f32(h.dr[0]), ord_f32(h.dr[1])), max(ord_f32(h.dr[2]), ord_f32(h.dr[3])));
     const bool d = (num == K) ? (od >= last) : (od != ORD_NEG_INF);
-    doubt = ((__ballot(d) >> (gi * G)) & gmask) != 0;  // group-uniform
+    doubt = group_bits<G>(__ballot(d), gi) != 0;  // group-uniform
     if (kth_o) *kth_o = (num == K) ? last : ORD_NEG_INF;  // ordered score of the K-th winner (anything counts while fewer than K are found)
     return num;
 }
@@ -894,13 +937,10 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
             best_ratio = shfl_f64(ratio, 0, G);
         }
         bool fail = mine && li > 0 && (ratio < best_ratio * (double)a.keep_factor);  // :998-1000
-        u64 fb = __ballot(fail);
-        u32 lane = threadIdx.x & 63;
-        u32 gshift = lane - li;  // first lane of the group
-        u64 gm = (G == 64) ? ~0ull : (((1ull << G) - 1) << gshift);
-        u64 failm = (fb & gm) >> gshift;
-        failm |= 1ull << numBest;
-        n_rows = __builtin_ctzll(failm);
+        const u32 lane = threadIdx.x & 63;
+        // (the failing ranks sit below numBest <= 16: 32 bits of the group's part of the ballot are all there is to look at)
+        const u32 failm = (u32)group_bits<G>(__ballot(fail), (lane - li) / (u32)G) | (1u << numBest);
+        n_rows = __builtin_ctz(failm);
         lwr = ratio;
         if (!(best >= a.ns_bound)) {  // :974
             n_rows = 0;
@@ -942,7 +982,6 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
     const u32 nb = a.db.n_branches;
     const u32 k = a.db.k;
     const float T = a.db.T;
-    const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
     constexpr bool FAST16 = (G >= 16 && !WIDE);  // buffer-addressed unit chunks (accumulate_units)
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     // chunk items the list can take (3U slots of slack for the read-ahead of accumulate_chunks)
@@ -1104,8 +1143,8 @@ __global__ void __launch_bounds__(256) place_packed_kernel(PlaceArgs a) {
                         const bool part = u >= u_lo && u < u_lo + per_part;
                         const bool hit = part && ((u32)desc[u] & DESC_LEN_MASK) != 0;
                         const u64 bal = __ballot(hit);
-                        const u64 sub = (bal >> (gi * G)) & gmask;
-                        if (hit) list[rc + __builtin_popcountll(sub & ((1ull << li) - 1))] = desc[u];
+                        const u64 sub = group_bits<G>(bal, gi);
+                        if (hit) list[rc + count_below<G>(sub, li)] = desc[u];
                         rc += __builtin_popcountll(sub);
                     }
                     if (li == 0) list[rc] = 0;  // sentinel: an empty row ends the cursor
@@ -1223,12 +1262,12 @@ __device__ __forceinline__ void record_codes(u32 recw, u32 pos, u32 li, u32 k, u
             code[u] = nbits == 32 ? c32 : (c32 & ((1u << nbits) - 1u));
             continue;
         }
-        u64 c = (((u64)w1 << 32) | w0) >> sh;
+        u32 w2 = 0u;
         if (BITS * 12 + 31 > 64) {
-            u32 w2 = __shfl(recw, (int)((wi + 2) & 15u), 16);
+            w2 = __shfl(recw, (int)((wi + 2) & 15u), 16);
             w2 = (wi + 2 < 16 && nbits + sh > 64) ? w2 : 0u;
-            c |= sh ? ((u64)w2 << (64 - sh)) : 0ull;
         }
+        const u64 c = funnel96(w0, w1, w2, sh);
         code[u] = nbits >= 64 ? c : (c & ((1ull << nbits) - 1));
     }
 }
@@ -1251,7 +1290,6 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
     const u32 nb = a.db.n_branches;
     const u32 k = a.db.k;
     const float T = a.db.T;
-    const u64 gmask = (1ull << G) - 1;
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     const int cap_items = (int)(a.list_cap * 2) - 3 * U - 2;
     const int cap_rows = (int)a.list_cap - 1;
@@ -1400,8 +1438,8 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
                         const bool part = u >= u_lo && u < u_lo + per_part;
                         const bool hit = part && ((u32)desc[u] & DESC_LEN_MASK) != 0;
                         const u64 bal = __ballot(hit);
-                        const u64 sub = (bal >> (gi * G)) & gmask;
-                        if (hit) list[rc + __builtin_popcountll(sub & ((1ull << li) - 1))] = desc[u];
+                        const u64 sub = group_bits<G>(bal, gi);
+                        if (hit) list[rc + count_below<G>(sub, li)] = desc[u];
                         rc += __builtin_popcountll(sub);
                     }
                     if (li == 0) list[rc] = 0;
@@ -1606,8 +1644,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     const u32 W = a.db.win_w, NWIN = a.db.n_win;
     const float T = a.db.T;
     const int K = (int)a.keep_at_most;  // <= 16 = one winner per lane (the host picks the dense kernels otherwise)
-    const u64 gmask = (1ull << G) - 1;
-    const u64 gmask_mine = gmask << (gi * G);  // this lane's group inside a wave ballot
+    // this lane's group inside a wave ballot (its 16 bits in place; two 32-bit halves: no 64-bit shift by a per-lane count)
+    const u64 gmask_mine = ((u64)(gi >= 2u ? 0xFFFFu << ((gi - 2u) * 16u) : 0u) << 32) | (u64)(gi < 2u ? 0xFFFFu << (gi * 16u) : 0u);
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     const int main_usable = (int)a.main_cap;
     const int work_usable = (int)a.work_cap - 3 * U - 2;
@@ -1726,7 +1764,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             mcnt = 0;
             overflow = false;
             all_items = 0;
-            const u64 range = (wb >= 64u ? 0ull : (1ull << wb)) - (1ull << wa);
+            const u64 range = bits_below(wb) & ~bits_below(wa);  // windows wa .. wb - 1
             for (u32 pos = 0; __any(pos < Q); pos += PU * G) {
                 u64 code[PU], desc[PU];
                 RawSlot raw[PU];
@@ -1739,7 +1777,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #pragma unroll
                 for (int u = 0; u < PU; u++) {
                     const u32 f = ws[u] & 63u, sp = ws[u] >> 6, l0 = sp == 3u ? 63u : f + sp, l = l0 < 63u ? l0 : 63u;
-                    const u64 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (2ull << l) - (1ull << f) : 0ull;  // bits f..l (l = 63: 2 << 63 wraps to 0)
+                    const u64 span = ((u32)desc[u] & DESC_LEN_MASK) != 0 ? (bits_below(l + 1u) & ~bits_below(f)) : 0ull;  // bits f..l
                     touched |= span;
                     nch[u] = (span & range) ? (((u32)desc[u] & DESC_LEN_MASK) + G - 1) >> 4 : 0u;  // <= 255 units (compact table)
                     all_items += nch[u];
@@ -1836,8 +1874,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
                         const u32 f = ws[u] & 63u, l = (ws[u] >> 6) == 3u ? 63u : f + (ws[u] >> 6);
                         const bool hit = ((u32)desc[u] & DESC_LEN_MASK) != 0 && f <= w && w <= l;
                         if (__any(rc + G > cap_rows)) flush_rows();
-                        const u64 sub = (__ballot(hit) >> (gi * G)) & gmask;
-                        if (hit) work64[rc + __builtin_popcountll(sub & ((1ull << li) - 1))] = desc[u];
+                        const u64 sub = group_bits<G>(__ballot(hit), gi);
+                        if (hit) work64[rc + count_below<G>(sub, li)] = desc[u];
                         rc += __builtin_popcountll(sub);
                     }
                 }
@@ -1862,7 +1900,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             }
             for (u32 part = 0; part < parts; part++) {
                 const u32 wa = part * NWIN / parts, wb = (part + 1) * NWIN / parts;
-                if (parts > 1 && !((tile_windows >> wa) & ((1ull << (wb - wa)) - 1ull))) continue;  // nothing in this range (or an empty one)
+                if (parts > 1 && !(tile_windows & bits_below(wb) & ~bits_below(wa))) continue;  // nothing in this range (or an empty one)
                 if (first || parts > 1) emit_range(wa, wb);  // (the exact pass of an unsplit tile finds its main list as the fast pass left it)
                 if (first) {
                     first = false;
@@ -1892,7 +1930,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
                     }
                 }
                 for (u32 w = wa; w < wb; w++) {
-                    if (!((tile_windows >> w) & 1ull)) continue;
+                    if (!lane_bit(tile_windows, w)) continue;
                     window_accumulate(w);
                     const u32 wlo = w * W;
                     const u32 win_n = nb - wlo < W ? nb - wlo : W;
@@ -1943,7 +1981,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
                 RK_STAMP(5);  // rounds
             }
         }
-        const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+        const int numBest = __builtin_popcountll(group_bits<G>(__ballot(acc_key != 0ull), gi));
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         RK_STAMP(6);  // redo of tiles in doubt
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
@@ -2001,7 +2039,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     const u32 W = a.db.win_w;
     const float T = a.db.T;
     const int K = (int)a.keep_at_most;
-    const u64 gmask = (1ull << G) - 1;
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     const u32 wpr = a.words_per_read;  // <= 16 (the host launches place_packed16w_kernel alone for longer records)
     const int list_usable = (int)a.main_cap - 3 * U;
@@ -2387,7 +2424,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
                 const int num = heads_rounds_raw<G, true>(hd, K, li, gi, win_o, win_i, d0, &kth_o);
                 acc_key = ((int)li < num) ? (((u64)win_o << 32) | (u64)(0xFFFFu - (win_i - 1u))) : 0ull;
                 const bool tie = tie_v != -INFINITY && ord_f32(tie_v) >= kth_o;
-                doubt = d0 || ((__ballot(tie) >> (gi * G)) & gmask) != 0;
+                doubt = d0 || group_bits<G>(__ballot(tie), gi) != 0;
 #ifdef RK_STAMPS
                 st_[13] += __any(d0) ? 1 : 0;   // (diagnostic: tiles in doubt because of a dropped candidate, as against a tie)
 #endif
@@ -2398,7 +2435,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
             st_[15] += 1;
 #endif
             {
-                const int num0 = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+                const int num0 = __builtin_popcountll(group_bits<G>(__ballot(acc_key != 0ull), gi));
                 u32 t_o = acc_key != 0ull ? ~(u32)(acc_key >> 32) : 0u;  // smallest ordered score among the winners = largest complement
                 t_o = group_max_u32<G>(t_o);
                 tau_o = num0 >= K ? ~t_o : 0u;  // (fewer than K found: everything is a candidate -- the tile then goes to the other kernel)
@@ -2440,7 +2477,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
 #endif
             continue;
         }
-        const int numBest = __builtin_popcountll((__ballot(acc_key != 0ull) >> (gi * G)) & gmask);
+        const int numBest = __builtin_popcountll(group_bits<G>(__ballot(acc_key != 0ull), gi));
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         RK_STAMP(6);  // redo of tiles in doubt
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
@@ -2772,7 +2809,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                         for (int e = 0; e < 4; e++) {
                             const bool cand = kk[e] != 0u && ord_f32(__uint_as_float(vv[e])) >= kth_o;
                             const u64 bal = __ballot(cand);
-                            const int idx = c + (int)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                            const int idx = c + (int)count_below<64>(bal, lane);
                             if (cand && idx < capc) cl[idx] = make_key(vv[e], (kk[e] & KEY_MASK) - 1u);
                             c += (int)__builtin_popcountll(bal);
                         }
@@ -3050,7 +3087,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                     hbase += w < wave ? c : 0u;
                     cnt += c;
                 }
-                if (hit) list[hbase + __builtin_popcountll(bal & ((1ull << lane) - 1))] = desc;
+                if (hit) list[hbase + count_below<64>(bal, lane)] = desc;
                 __syncthreads();
                 RK_STAMP(1);  // compaction of the hits (two barriers)
                 // ---- accumulate: every wave applies its branch range of every row, rows in k-mer order ----
@@ -3217,8 +3254,8 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
     const u32 W1 = m.alt_count[cls], W2 = two ? m.alt_count[cls2] : 1u;
     const u32 W = W1 * W2;
     auto word = [&](u32 w) {
-        u64 cw = code | ((u64)m.alt_table[cls * 20 + w % W1] << (BITS * p));
-        if (two) cw |= (u64)m.alt_table[cls2 * 20 + w % W2] << (BITS * p2);
+        u64 cw = code | place_bits(m.alt_table[cls * 20 + w % W1], BITS * p);
+        if (two) cw |= place_bits(m.alt_table[cls2 * 20 + w % W2], BITS * p2);
         return cw;
     };
     auto rebase = [&](u32 &x) { const u32 xw = x - s_lo; x = (xw < nb) ? xw : 0xFFFFu; };  // (padding 0xFFFF stays 0xFFFF)
@@ -3230,7 +3267,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             if (have_pre) d[w] = pre[w];  // looked up with the block's other ambiguous positions (place_ascii_kernel)
-            else d[w] = ((u32)w < W) ? lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p))) : 0ull;
+            else d[w] = ((u32)w < W) ? lookup_desc<BITS, TM>(a.db, code | place_bits(m.alt_table[cls * 20 + w], BITS * p)) : 0ull;
         }
         const u32 maxlen = max(max((u32)d[0] & DESC_LEN_MASK, (u32)d[1] & DESC_LEN_MASK),
                                max((u32)d[2] & DESC_LEN_MASK, (u32)d[3] & DESC_LEN_MASK));
@@ -3518,7 +3555,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                             const u32 src = lane + i;
                             const u32 got = (u32)__shfl((int)pair, (int)(src & 63u), 64);
                             const u32 c = (src < 64u ? got : got >> 8) & 0xFFu;
-                            code |= (u64)((c & 0x80) ? 0u : c) << (BITS * i);
+                            code |= place_bits((c & 0x80) ? 0u : c, BITS * i);
                             ambmask |= ((c >> 7) & 1u) << i;
                         }
                         if (!inr) { code = 0; ambmask = 0; }
@@ -3539,7 +3576,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                             pre_ok = true;
 #pragma unroll
                             for (int w = 0; w < 4; w++)
-                                if ((u32)w < W) alt_d[w] = lookup_desc<BITS, TM>(a.db, code | ((u64)m.alt_table[cls * 20 + w] << (BITS * p)));
+                                if ((u32)w < W) alt_d[w] = lookup_desc<BITS, TM>(a.db, code | place_bits(m.alt_table[cls * 20 + w], BITS * p));
                         }
                     }
                     u64 amb_b = __ballot(inr && ambmask != 0);
@@ -3548,13 +3585,12 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     RK_STAMP(1);  // decode + probes of the batch
                     while (true) {  // wave-uniform: runs of unambiguous positions separated by ambiguous ones
                         const u32 na = amb_b ? (u32)__builtin_ctzll(amb_b) : 64u;
-                        const u64 below_na = na >= 64 ? ~0ull : ((1ull << na) - 1);
-                        const u64 hb = hit_b & below_na & ~((1ull << p0) - 1);
+                        const u64 hb = hit_b & bits_below((u32)na) & ~bits_below((u32)p0);
                         const int nh = __builtin_popcountll(hb);
                         if (cnt + nh > cap) flush();
-                        if ((hb >> lane) & 1ull) clist[cnt + __builtin_popcountll(hb & ((1ull << lane) - 1))] = desc;
+                        if (lane_bit(hb, lane)) clist[cnt + count_below<64>(hb, lane)] = desc;
                         cnt += nh;
-                        any_long = any_long || __any(((hb >> lane) & 1ull) && ((u32)desc & DESC_LEN_MASK) > 64u);
+                        any_long = any_long || __any(lane_bit(hb, lane) && ((u32)desc & DESC_LEN_MASK) > 64u);
                         RK_STAMP(2);  // list building
                         if (na >= 64) break;
                         flush();  // everything before the ambiguous k-mer must be applied first
