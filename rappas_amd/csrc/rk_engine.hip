@@ -1447,13 +1447,14 @@ struct TileOrder {
 #endif
 constexpr uint32_t RK_HASH_LOG_SLOTS = RK_HASH_LOGS, RK_HASH_MAIN_CAP = 320;
 #ifndef RK_HASH_KEY_SLACK
-#define RK_HASH_KEY_SLACK 192u  // slots kept free: a table takes NS - this many keys before a step (profiles/r04_hash_knobs.txt)
+#define RK_HASH_KEY_SLACK 48u  // slots kept free: a read's table takes NS - this many keys (the kernel counts a step's entries before it takes the step)
 #endif
 // From this many branches on place_hash64_kernel is ahead of place_packed16s_kernel, whose cost grows with the windows a tree is cut
-// into (profiles/r04_hash_crossover.txt; C2-like rows, Mreads/s hash / sorted-stream: 19 999 branches 88 / 102, 39 999: 84 / 68,
-// 65 535: 80 / 34; clade-shaped reads 79 / 121 at 19 999, 79 / 45 at 65 535)
+// into (profiles/r04_hash_crossover.txt; C2-like rows, Mreads/s hash / sorted-stream: 28 001 branches 88 / 92, 39 999: 87 / 69,
+// 65 535: 87 / 34; clade-shaped reads 81 / 111 at 28 001, 80 / 89 at 39 999, 80 / 45 at 65 535: uniform reads cross at ~30 000,
+// clade-shaped ones at ~45 000, the rule sits between)
 #ifndef RK_HASH_MIN_BRANCHES
-#define RK_HASH_MIN_BRANCHES 28000u
+#define RK_HASH_MIN_BRANCHES 36000u
 #endif
 static bool hash_tree(const rk_db *db) {  // images whose tiles go to place_hash64_kernel first
     if (rk_knob("RK_NO_HASH") || rk_knob("RK_NO_WSTREAM") || db->info.rows_bytes >= ROWS_FIT32_LIMIT) return false;
@@ -1464,7 +1465,7 @@ static uint32_t hash_key_limit() {
     uint32_t slack = RK_HASH_KEY_SLACK;
     if (const char *e = rk_knob("RK_HASH_KEY_SLACK")) slack = (uint32_t)atoi(e);  // developer knob
     const uint32_t ns = 1u << RK_HASH_LOG_SLOTS;
-    if (slack < 64u * RK_HNPL + 16u) slack = 64u * RK_HNPL + 16u;  // a step adds up to 64 keys per entry of a lane: the table is never full
+    if (slack < 16u) slack = 16u;
     if (slack > ns - 64u) slack = ns - 64u;
     return ns - slack;
 }

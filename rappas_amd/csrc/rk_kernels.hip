@@ -2532,7 +2532,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     const int cap_items = (int)a.main_cap - 12 * U * NPL - 8;  // fillers behind the last step + the read-ahead of the ring
     const int capc = (int)(a.main_cap / 2) - 16;         // candidate keys of a read in doubt (u64), the last 16 = the winners
-    const u32 key_limit = a.work_cap;                    // keys a table takes before a step (the step adds <= 64 NPL: never full)
+    const u32 key_limit = a.work_cap;                    // keys the table may hold (< NS: a probe always finds an empty slot)
 #ifdef RK_STAMPS
     unsigned long long st_[16] = {0}, t_ = rk_now();
 #endif
@@ -2595,7 +2595,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
             //      Written without divergent control flow: lanes without an entry (padding of a unit, a filler item) work on a word
             //      of their own behind the table, lanes that have found their slot repeat a compare-and-swap that changes nothing ----
             auto apply = [&](const u32 (&sbv)[NPL], const float (&scv)[NPL]) {
-                if (n_keys > key_limit || stamp >= 0xFFFEu) over = true;  // (the stamp has 16 bits)
+                if (stamp >= 0xFFFEu) over = true;  // (the stamp has 16 bits)
                 if (over) return;
                 // h[p]: BYTE offset of the entry's slot in the LDS (keys at 0, the lane's own word at 4 (NS + lane)).  Conditions are kept
                 // as wave masks in SGPRs and combined there (hipcc turns a bool that feeds both a select and a ballot into a 0 / 1
@@ -2609,6 +2609,12 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                     act[p] = ~mask_eq0(key[p]);
                     h[p] = mask_select(own, ((key[p] * 0x9E3779B1u) >> (32 - LOGS)) << 2, act[p]);
                     fresh[p] = 0ull;
+                }
+                {   // the table takes this step only if it cannot fill up: keys so far + the step's entries (each may be a new key)
+                    u32 n_act = 0;
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) n_act += (u32)__builtin_popcountll(act[p]);
+                    if (n_keys + n_act > key_limit) { over = true; return; }
                 }
 #ifdef RK_STAMPS
                 st_[15] += 1;

@@ -923,7 +923,7 @@ def test_hash_kernel_units_of_a_step_that_meet_in_a_branch(n_branches, monkeypat
 def test_short_row_kernels_of_big_trees_with_scores_from_a_handful_of_values(seed, kernel, request, monkeypatch):
     """equal sums everywhere: every score of the database is one of eight values (dyadic fractions of the threshold, so that sums of
     them collide exactly), on windowed trees of 4 501 ... 65 535 branches, keep_at_most 1 ... 16.  The stream heads of
-    place_hash64_kernel (the product's choice beyond 28 000 branches; RK_HASH_ALWAYS) and of place_packed16s_kernel (RK_NO_HASH) are fed in any branch order; a tie that
+    place_hash64_kernel (the product's choice beyond 36 000 branches; RK_HASH_ALWAYS) and of place_packed16s_kernel (RK_NO_HASH) are fed in any branch order; a tie that
     could be among the K best has to send the read through the exact ranking (or to place_packed16w_kernel) -- the result must be the
     oracle's branch for branch wherever the oracle's own order is defined (tests/util.py compares exact ties as sets)."""
     import dataclasses
