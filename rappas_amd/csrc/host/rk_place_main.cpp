@@ -356,6 +356,7 @@ int main(int argc, char **argv) {
         }
 
         // ---- the one-string-at-a-time path of rk_hostio.hpp (the definition the fast path is held to) ----
+        const double tc0 = now();
         const std::vector<rkh::Fasta> records = rkh::read_fasta(slurp(fasta));
         const rkh::Dedup dd = rkh::dedup_index(records);
         const std::vector<std::vector<std::string>> names = rkh::dedup_names(records, dd);
@@ -386,6 +387,7 @@ int main(int argc, char **argv) {
             nf << rkh::notplaced_log(records, dd, flags.data());
         }
         std::cerr << n << " unique reads, " << pl.size() << " placed -> " << out << "\n";
+        if (timing) std::cout << "{\"reads\": " << records.size() << ", \"unique\": " << n << ", \"db_s\": " << (t_db - t_start) << ", \"fasta_to_jplace_s\": " << (now() - tc0) << ", \"classic\": true}" << std::endl;
         return 0;
     } catch (const std::exception &e) {
         std::cerr << "rk_place: " << e.what() << "\n";
