@@ -234,3 +234,65 @@ JNIEXPORT void JNICALL Java_core_algos_NativePlacement_placeBatchMulti(JNIEnv *e
     if (null_handle) { THROW_ARG("placeBatchMulti: null database handle"); return; }
     place_common(env, handles, (uint32_t)nd, seqs, offs, keepAtMost, keepFactor, ambMode, nsBound, nRows, branch, score, lwr, flags);
 }
+
+/* ---- round 4: the HBM image as a file (rk_db_save / rk_db_load / rk_db_image_user) and the first call's set-up ahead of time ----
+ * void dbSave(long db, String path, byte[] user) */
+JNIEXPORT void JNICALL Java_core_algos_NativePlacement_dbSave(JNIEnv *env, jclass cls, jlong db, jstring path, jbyteArray user) {
+    (void)cls;
+    if (!db || !path) { THROW_ARG("dbSave: null handle or path"); return; }
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    if (!p) return;
+    jsize ulen = user ? (*env)->GetArrayLength(env, user) : 0;
+    jbyte *u = ulen ? (*env)->GetByteArrayElements(env, user, NULL) : NULL;
+    if (ulen && !u) { (*env)->ReleaseStringUTFChars(env, path, p); return; }
+    const int rc = rk_db_save((rk_db *)(intptr_t)db, p, u, (uint64_t)ulen);
+    if (u) (*env)->ReleaseByteArrayElements(env, user, u, JNI_ABORT);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc != RK_OK) throw_rk(env, "rk_db_save");
+}
+
+/* long dbLoad(String path, int device) */
+JNIEXPORT jlong JNICALL Java_core_algos_NativePlacement_dbLoad(JNIEnv *env, jclass cls, jstring path, jint device) {
+    (void)cls;
+    if (!path) { THROW_ARG("dbLoad: null path"); return 0; }
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    if (!p) return 0;
+    rk_db *db = NULL;
+    const int rc = rk_db_load(p, (int)device, &db);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc != RK_OK) { throw_rk(env, "rk_db_load"); return 0; }
+    return (jlong)(intptr_t)db;
+}
+
+/* byte[] dbImageUser(String path): the caller's blob of an image file (the drivers keep the reference tree there) */
+JNIEXPORT jbyteArray JNICALL Java_core_algos_NativePlacement_dbImageUser(JNIEnv *env, jclass cls, jstring path) {
+    (void)cls;
+    if (!path) { THROW_ARG("dbImageUser: null path"); return NULL; }
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    if (!p) return NULL;
+    uint64_t len = 0;
+    jbyteArray out = NULL;
+    if (rk_db_image_user(p, NULL, 0, &len) != RK_OK) {
+        throw_rk(env, "rk_db_image_user");
+    } else if (len > 0x7FFFFFF0ull) {
+        THROW_ARG("dbImageUser: blob larger than a Java array");
+    } else if ((out = (*env)->NewByteArray(env, (jsize)len)) != NULL && len) {
+        jbyte *b = (*env)->GetByteArrayElements(env, out, NULL);
+        if (b) {
+            const int rc = rk_db_image_user(p, b, len, &len);
+            (*env)->ReleaseByteArrayElements(env, out, b, 0);
+            if (rc != RK_OK) { throw_rk(env, "rk_db_image_user"); out = NULL; }
+        } else {
+            out = NULL;
+        }
+    }
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    return out;
+}
+
+/* void reserveHostPath(long db, int keepAtMost, int maxReadLen) */
+JNIEXPORT void JNICALL Java_core_algos_NativePlacement_reserveHostPath(JNIEnv *env, jclass cls, jlong db, jint keepAtMost, jint maxReadLen) {
+    (void)cls;
+    if (!db || keepAtMost < 1 || maxReadLen < 1) { THROW_ARG("reserveHostPath: bad argument"); return; }
+    if (rk_reserve_host_path((rk_db *)(intptr_t)db, (uint32_t)keepAtMost, (uint32_t)maxReadLen) != RK_OK) throw_rk(env, "rk_reserve_host_path");
+}
