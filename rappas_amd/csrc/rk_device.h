@@ -87,6 +87,8 @@ struct PlaceArgs {
                                 // batch's order -- is left to place_packed16w_kernel by the kernel launched ahead of it (never the caller's flag array:
                                 // d_flags_in may be the same buffer as the output flags)
     const u32 *perm;         // tile t holds reads perm[4t .. 4t+3] (reads grouped by their place in the tree); null = in order
+    u32 *marked_list;        // [<= n_tiles] the marked tiles as a list (compact_marks_kernel) for the second launch, or nullptr: it scans tile_marks
+    u32 *marked_ctl;         // {number of tiles in marked_list, head of the queue the second launch's waves take them from}, zeroed with the marks
     const u32 *keep_order;   // with perm: *keep_order != 0 = the pre-pass found a batch of reads without a clade and left perm unwritten
 };
 

@@ -1413,18 +1413,25 @@ struct TileOrder {
         if (!retile && !want_marks) return RK_OK;
         const size_t n_tiles = (size_t)((a.n_reads + 3) / 4);
         const size_t marks_off = 1024, perm_off = marks_off + (want_marks ? ((n_tiles + 255) & ~(size_t)255) : 0);
-        const size_t keys_off = perm_off + (retile ? (((size_t)a.n_reads * 4 + 255) & ~(size_t)255) : 0), total = keys_off + (retile ? a.n_reads : 0);
+        const size_t keys_off = perm_off + (retile ? (((size_t)a.n_reads * 4 + 255) & ~(size_t)255) : 0);
+        // (the marked tiles as a list + the queue's two counters, in front of the marks: place_packed16w_kernel as the second launch)
+        const bool want_list = want_marks && n_tiles < (1ull << 32);
+        const size_t list_off = (keys_off + (retile ? a.n_reads : 0) + 255) & ~(size_t)255, total = list_off + (want_list ? n_tiles * 4 : 0);
         unsigned char *base = (unsigned char *)launch_scratch(db, s, total);
         if (!base) return RK_OK;
         if (want_marks) {
             marks = base + marks_off;
-            HIP_TRY(hipMemsetAsync(marks, 0, n_tiles, s));
+            HIP_TRY(hipMemsetAsync(marks - 8, 0, n_tiles + 8, s));
             a.tile_marks = marks;
+            if (want_list) {
+                a.marked_ctl = (uint32_t *)(marks - 8);
+                a.marked_list = (uint32_t *)(base + list_off);
+            }
         }
         if (!retile) return RK_OK;
         uint32_t *hist = (uint32_t *)base, *cursor = hist + 128, *perm = (uint32_t *)(base + perm_off);
         unsigned char *keys = base + keys_off;
-        HIP_TRY(hipMemsetAsync(base, 0, marks_off, s));
+        HIP_TRY(hipMemsetAsync(base, 0, marks_off - 8, s));  // (the last 8 bytes: the hand-over queue's counters, zeroed with the marks)
         const unsigned nblk = (unsigned)std::min<uint64_t>((a.n_reads + 255) / 256, 2048);  // (grid-stride: a batch that keeps its order ends 2 048 blocks, not a million threads)
         const unsigned sblk = (unsigned)((a.n_reads / 64 + 255) / 256 + 1);
         if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_sample_kernel<2>, dim3(sblk), dim3(256), 0, s, a, hist);
@@ -1556,6 +1563,11 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     }
     // ---- place_packed16w_kernel: every tile (records of more than 16 words), or the tiles the first kernel handed over ----
     a.only_marked = ((hash_first || sorted_first) && first_ok) ? 1u : 0u;
+    if (a.only_marked && a.marked_list) {
+        const unsigned nblk = (unsigned)std::min<uint64_t>((n_tiles + 255) / 256, 1024);
+        hipLaunchKernelGGL(compact_marks_kernel, dim3(nblk), dim3(256), 0, stream, (const unsigned char *)a.tile_marks, n_tiles, a.marked_list, a.marked_ctl);
+        HIP_TRY(hipGetLastError());
+    }
     // 88 words = the 44 keys the exact select of a window needs as scratch for keep_at_most <= 8 (K + 16 candidates + 16 winners); 96 beyond
     const uint32_t work_min = a.keep_at_most > 8 ? 96u : 88u;
     if (wp.work_cap < work_min) {

@@ -1625,6 +1625,23 @@ __global__ void __launch_bounds__(256) retile_scatter_kernel(u64 n_reads, const 
     }
 }
 
+// The tiles a first kernel marked, as a list (any order: a tile's results do not depend on when it is placed); ctl[0] = their number.
+__global__ void __launch_bounds__(256) compact_marks_kernel(const unsigned char *marks, u64 n_tiles, u32 *list, u32 *ctl) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 rounds = (n_tiles + stride - 1) / stride;  // (every lane takes every round: the ballots need whole waves)
+    for (u64 it = 0; it < rounds; it++) {
+        const u64 t = it * stride + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool m = t < n_tiles && marks[t] != 0;
+        const u64 bal = __ballot(m);
+        if (bal == 0ull) continue;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&ctl[0], (u32)__builtin_popcountll(bal));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (m) list[base + count_below<64>(bal, lane)] = (u32)t;
+    }
+}
+
 template <int BITS, int U, int PU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16w_kernel(PlaceArgs a) {  // (amino acids: 286 registers left to itself = one wave per SIMD; DNA: 219, and slower when asked for two)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT;
@@ -1724,13 +1741,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
     // accumulate ring into scratch spills, which serialise it; with 3-16 window passes per tile the probe latency is small change.)
     u32 c_recw, c_R, c_fin;
     bool c_have;
-    load_tile(wave_global, c_recw, c_R, c_fin, c_have);
+    // Second launch behind place_packed16s_kernel / place_hash64_kernel: only the tiles they handed over.  With a list of them
+    // (compact_marks_kernel) the waves take the next tile from one queue -- a handful of tiles of ~0.4 ms each on a 65 535-branch tree,
+    // which a fixed tile -> wave assignment left to a few waves; every wave ends when the queue's head passes the list's length.
+    const bool queued = a.only_marked != 0u && a.marked_list != nullptr;
+    auto take_marked = [&]() -> u64 {
+        u32 i = 0;
+        if (lane == 0) i = atomicAdd(&a.marked_ctl[1], 1u);
+        i = (u32)__builtin_amdgcn_readfirstlane((int)i);
+        const u32 n_marked = (u32)__builtin_amdgcn_readfirstlane((int)a.marked_ctl[0]);
+        return i < n_marked ? (u64)(u32)__builtin_amdgcn_readfirstlane((int)a.marked_list[i]) : n_tiles;
+    };
+    u64 tile = queued ? take_marked() : wave_global;
+    load_tile(tile, c_recw, c_R, c_fin, c_have);
 
-    for (u64 tile = wave_global; tile < n_tiles; tile += wave_count) {
-        if (a.only_marked) {  // second launch behind place_packed16s_kernel / place_hash64_kernel: only the tiles they handed over
+    while (tile < n_tiles) {
+        if (a.only_marked && !queued) {  // (no list: every wave looks at the marks of its own tiles)
             const u32 mark = a.tile_marks[tile];
             if (!__builtin_amdgcn_readfirstlane((int)mark)) {
-                load_tile(tile + wave_count, c_recw, c_R, c_fin, c_have);
+                tile += wave_count;
+                load_tile(tile, c_recw, c_R, c_fin, c_have);
                 continue;
             }
         }
@@ -1985,7 +2015,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS =
         const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
         RK_STAMP(6);  // redo of tiles in doubt
         if (have && !deferred) weigh_and_store<G>(a, r, li, numBest, acc_key, flags);
-        c_recw = n_recw; c_R = n_R; c_fin = n_fin; c_have = n_have;
+        if (queued) {
+            tile = take_marked();
+            load_tile(tile, c_recw, c_R, c_fin, c_have);
+        } else {
+            tile += wave_count;
+            c_recw = n_recw; c_R = n_R; c_fin = n_fin; c_have = n_have;  // (loaded behind this tile's probe)
+        }
         RK_STAMP(7);  // weigh + store
     }
 #ifdef RK_STAMPS
