@@ -30,7 +30,7 @@
 #define RK_HEADS_MAX_K 16  // the fast select (stream heads) up to this keep_at_most (C2: K = 9 ... 16 run at 343 ... 274 Mreads/s with it, 280 ... 117 through the exact two-pass scan)
 #endif
 #ifndef RK_ABLATE
-#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate, 512 / 1024 / 2048 = windowed kernel without accumulate / with the exact select only in the last window / without compaction and accumulate (outputs are then wrong), 4096 = windowed kernel without skipping untouched windows (outputs stay right)
+#define RK_ABLATE 0  // timing-only dev builds: 1 = no accumulate, 2 = no select, 4 = no LWR, 8 = no LDS update, 16 = one cached row line, 32 = one unit per row, 128 / 256 = ambiguity kernel without amb_position / without its row accumulate, 512 / 1024 / 2048 = windowed kernel without accumulate / with the exact select only in the last window / without compaction and accumulate (outputs are then wrong), 4096 = windowed kernel without skipping untouched windows (outputs stay right), 8192 = no result stores
 #endif
 #include "../../include/rappas_place.h"
 
@@ -946,6 +946,10 @@ __device__ __forceinline__ void weigh_and_store(const PlaceArgs &a, u64 r, u32 l
             n_rows = 0;
             flags |= RK_FLAG_BELOW_NSBOUND;
         }
+    }
+    if (RK_ABLATE & 8192) {  // timing only: everything but the stores
+        asm volatile("" : : "v"(branch), "v"(score), "v"(lwr), "v"(n_rows), "v"(flags));
+        return;
     }
     if ((int)li < K) {
         bool on = (int)li < n_rows;
@@ -3054,6 +3058,11 @@ __device__ __forceinline__ int select_rounds64(const u32 *S, u32 base, u32 s0, u
     return num;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's global stores (s_waitcnt vmcnt(0)) --
+// in place_wg_kernel that made the whole workgroup wait for the result rows of the read just placed to reach memory, which nobody
+// in the workgroup reads.  Waves exchange data through the LDS alone there.
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int BITS, int TM, bool WIDE, int U>
 __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
     extern __shared__ u32 lds[];
@@ -3079,7 +3088,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
     const uint4 *S4 = (const uint4 *)S;
     const uint4 reset4 = make_uint4(S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED, S_UNTOUCHED);
     for (u32 i = tid; i < a.s_stride; i += blockDim.x) S[i] = S_UNTOUCHED;
-    __syncthreads();
+    wg_barrier_lds();
 #ifdef RK_STAMPS
     unsigned long long st_[16] = {0}, t_ = rk_now();
 #endif
@@ -3122,7 +3131,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                 RK_STAMP(0);  // probe (record words, table)
                 const u64 bal = __ballot(hit);
                 if (lane == 0) wcnt[wave] = (u32)__builtin_popcountll(bal);
-                __syncthreads();
+                wg_barrier_lds();
                 u32 hbase = 0, cnt = 0;
                 for (u32 w = 0; w < NW; w++) {
                     const u32 c = wcnt[w];
@@ -3130,7 +3139,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                     cnt += c;
                 }
                 if (hit) list[hbase + count_below<64>(bal, lane)] = desc;
-                __syncthreads();
+                wg_barrier_lds();
                 RK_STAMP(1);  // compaction of the hits (two barriers)
                 // ---- accumulate: every wave applies its branch range of every row, rows in k-mer order ----
                 // every wave's slices of the batch's rows first (the only reads of the hit list), then a barrier: from here on the list
@@ -3138,11 +3147,11 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                 const bool work = cnt > 0 && q_hi > q_lo;
                 WaveSlices<WIDE> ws;
                 if (work) wave_slices<WIDE>(ws, list, (int)cnt, lane, q_lo, q_hi, a.db.rows);
-                __syncthreads();
+                wg_barrier_lds();
                 RK_STAMP(3);  // slices of the batch's rows (index lines)
                 if (work) wave_accumulate<WIDE, U>(S, win, base, ws, lane, a.db.rows, QT, T);
                 RK_STAMP(2);  // accumulate (this wave's branch range)
-                if (pos0 + batch < Q) __syncthreads();  // (the list is rewritten by the next batch's probe)
+                if (pos0 + batch < Q) wg_barrier_lds();  // (the list is rewritten by the next batch's probe)
             }
 
             // ---- select, level 1: every wave ranks its segment of S (stream heads as in select_topk, K rounds of wave max) ----
@@ -3210,7 +3219,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                         if (4 * q + e >= s0 && 4 * q + e < s1) S[4 * q + e] = S_UNTOUCHED;
             }
             RK_STAMP(4);  // level-1 select of this wave's segment
-            __syncthreads();
+            wg_barrier_lds();
             RK_STAMP(5);  // barrier behind it
         }
         // ---- select, level 2 (wave 0): exact top-K of the n_pass*NW*K wave winners, then weights and output rows ----
@@ -3244,11 +3253,12 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
                 numBest = __builtin_popcountll(__ballot(win_key != 0));
             }
             const bool deferred = is_amb && a.has_ascii && !rejected;  // the ASCII kernel writes these
+            RK_STAMP(8);  // level-2 select (wave 0)
             // (keep_at_most <= 16: the winners sit in the wave's first 16-lane row -- the DPP form of the weighing)
             if (!deferred) weigh_and_store<16>(a, r, lane, numBest, win_key, flags);
         }
-        RK_STAMP(6);  // level-2 select + weights + store (wave 0)
-        __syncthreads();
+        RK_STAMP(6);  // weights + store (wave 0)
+        wg_barrier_lds();
         RK_STAMP(7);  // the other waves waiting for it
 #ifdef RK_STAMPS
         st_[11] += 1;

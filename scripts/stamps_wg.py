@@ -34,8 +34,8 @@ for nb in arg("branches", [15999]):
         for w, nm in ((0, "wave 0"), (1, "last wave")):
             s = a[w::2]
             s = s[s[:, 11] > 0]
-            t, tot = s[:, 11].sum(), s[:, :8].sum()
+            t, tot = s[:, 11].sum(), s[:, :9].sum()
             print(f"  {nm}: segments whose stream heads were in doubt {s[:, 12].sum() / t:.3f} a read, of those through the K-pass fallback {s[:, 13].sum() / t:.3f}")
             print(f"  {nm}: {tot / t:9.0f} cycles per read: " + "  ".join(f"{nmx} {s[:, i].sum() / t:6.0f}" for i, nmx in enumerate(
-                ["probe", "compact", "accumulate", "wait(acc)", "select-1", "barrier", "select-2+store", "wait(sel-2)"])))
+                ["probe", "compact", "accumulate", "slices", "select-1", "barrier", "weigh+store", "wait(sel-2)", "select-2"])))
         db.close()
