@@ -650,6 +650,9 @@ def main():
     H_total, hit_kmers = count_entries_torch(torch, lens_table, alphabet, k, bits, packed, rlen)
     H_mean = H_total / n_reads
     B = math.ceil(rlen * bits / 8) + Q * 8 + H_mean * 6 + (2 + K * 14)
+    # the engine's own count of the same quantities (rk_count_work_device: a kernel of its own) next to the torch count above
+    work = pp.count_work(packed, fixed_len=rlen)
+    work["equals_independent_count"] = bool(work["entries"] == H_total and work["kmers_hit"] == hit_kmers and work["kmers_probed"] == n_reads * Q)
 
     for _ in range(a.warmup):
         step()
@@ -709,6 +712,7 @@ def main():
                          "traffic": traffic, "bytes_per_read": B, "entries_per_read": H_mean,
                          "kernel_ms": kern_avg_s * 1e3, "kernel": db.kernel_name().split("<")[0]},
             "verified_vs_oracle": verified,
+            "work_counters": work,
         }
         line.update(per_rank_fields(sync, per_rank))
         line["n_gpus_visible"] = torch.cuda.device_count()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RK_VERSION 101 /* 0.1.1: rk_db_save / rk_db_save_desc / rk_db_load / rk_db_image_info / rk_db_image_user, rk_reserve_host_path, RK_ERR_IO */
+#define RK_VERSION 101 /* 0.1.1: rk_db_save / rk_db_save_desc / rk_db_load / rk_db_image_info / rk_db_image_user, rk_reserve_host_path, rk_count_work_device, RK_ERR_IO */
 
 /* alphabets = number of unambiguous states (States.getNonAmbiguousStatesCount()) */
 #define RK_ALPHABET_DNA 4  /* src/core/DNAStatesShifted.java : A=0 T/U=1 C=2 G=3, 2 bits/base   */
@@ -240,6 +240,17 @@ int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_reads, cons
                            uint32_t words_per_read, const uint32_t *d_lens, uint32_t fixed_len,
                            const uint32_t *d_flags_in, const uint8_t *d_seq_ascii, const uint64_t *d_seq_off,
                            const rk_result *d_out, void *stream);
+
+/* Optional diagnostics (round 4): the work a batch of packed reads asks of the database, counted by a kernel of its own -- the
+ * placement kernels carry no counters.  kmers_probed = sum of sk.getMerCount() (AmbigSequenceKnife.java:191) over the reads the
+ * packed kernels place (not BAD_CHAR / TOO_LONG / AMBIGUOUS, at least k symbols); kmers_hit = those with a row in the database
+ * (hash.getPairsOfTopPosition2(word) != null, PlacementProcess.java:705-707); entries = (branch, score) pairs of those rows, i.e.
+ * iterations of the loop at PlacementProcess.java:719-735.  d_out is device memory (zeroed by the call on `stream`, then filled). */
+typedef struct rk_work {
+    uint64_t kmers_probed, kmers_hit, entries;
+} rk_work;
+int rk_count_work_device(rk_db *db, uint64_t n_reads, const uint32_t *d_packed, uint32_t words_per_read, const uint32_t *d_lens,
+                         uint32_t fixed_len, const uint32_t *d_flags_in, rk_work *d_out, void *stream);
 
 /* Launch geometry knob (0 = auto): lanes cooperating on one read (8,16,32,64). For tuning/benchmarks. */
 int rk_set_lanes_per_read(rk_db *db, uint32_t lanes);

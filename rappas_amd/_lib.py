@@ -104,6 +104,7 @@ EXPORTS = {
     "rk_place_packed_device": (C.c_int, [C.c_void_p, C.POINTER(rk_params), C.c_uint64, C.c_void_p, C.c_uint32,
                                          C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(rk_result), C.c_void_p]),
+    "rk_count_work_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rk_set_lanes_per_read": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rk_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rk_build_db": (C.c_int, [C.POINTER(rk_build_desc), C.POINTER(rk_built_db)]),

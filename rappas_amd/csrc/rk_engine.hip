@@ -1875,6 +1875,36 @@ extern "C" int rk_place_packed_device(rk_db *db, const rk_params *p, uint64_t n_
     return RK_OK;
 }
 
+// rk_count_work_device: the work a batch asks of the database (count_work_kernel), for callers that want the reference's own
+// diagnostics -- k-mers looked up, k-mers found, row entries walked -- next to the placements.  Opt-in and separate: the placement
+// kernels carry no counters.
+template <int BITS>
+static void launch_count(const rk_db *db, const uint32_t *d_packed, uint32_t wpr, const uint32_t *d_lens, uint32_t fixed_len, const uint32_t *d_flags_in,
+                         uint64_t n_reads, unsigned long long *d_out, hipStream_t s) {
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 3) / 4, (uint64_t)db->cu_count * 8);
+    switch (db->info.table_mode) {
+    case RK_TABLE_DIRECT: hipLaunchKernelGGL((count_work_kernel<BITS, TM_COMPACT>), dim3(blocks), dim3(256), 0, s, db->view, d_packed, wpr, d_lens, fixed_len, d_flags_in, n_reads, d_out); break;
+    case RK_TABLE_DIRECT8: hipLaunchKernelGGL((count_work_kernel<BITS, TM_DIRECT8>), dim3(blocks), dim3(256), 0, s, db->view, d_packed, wpr, d_lens, fixed_len, d_flags_in, n_reads, d_out); break;
+    default: hipLaunchKernelGGL((count_work_kernel<BITS, TM_HASH>), dim3(blocks), dim3(256), 0, s, db->view, d_packed, wpr, d_lens, fixed_len, d_flags_in, n_reads, d_out); break;
+    }
+}
+extern "C" int rk_count_work_device(rk_db *db, uint64_t n_reads, const uint32_t *d_packed, uint32_t words_per_read, const uint32_t *d_lens,
+                                    uint32_t fixed_len, const uint32_t *d_flags_in, rk_work *d_out, void *stream) {
+    if (!db || !d_out) return fail(RK_ERR_INVALID, "rk_count_work_device: null argument");
+    HIP_TRY(hipSetDevice(db->info.device));
+    hipStream_t s = (hipStream_t)stream;
+    static_assert(sizeof(rk_work) == 3 * sizeof(unsigned long long), "rk_work is three 64-bit counters");
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(rk_work), s));
+    if (n_reads == 0) return RK_OK;
+    if (!d_packed || words_per_read == 0) return fail(RK_ERR_INVALID, "rk_count_work_device: null packed reads");
+    if (!d_lens && (uint64_t)fixed_len * db->info.bits_per_symbol > (uint64_t)words_per_read * 32)
+        return fail(RK_ERR_INVALID, "rk_count_work_device: fixed_len=%u does not fit %u words", fixed_len, words_per_read);
+    if (db->info.bits_per_symbol == 2) launch_count<2>(db, d_packed, words_per_read, d_lens, fixed_len, d_flags_in, n_reads, (unsigned long long *)d_out, s);
+    else launch_count<5>(db, d_packed, words_per_read, d_lens, fixed_len, d_flags_in, n_reads, (unsigned long long *)d_out, s);
+    HIP_TRY(hipGetLastError());
+    return RK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-buffer entry point: chunked, two workspaces on two streams so that the upload of chunk c+1 overlaps the
 // kernels / download of chunk c; device buffers are kept (grow-only) in the rk_db between calls

@@ -3706,6 +3706,58 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
 }
 
 // ------------------------------------------------------------------------------------------------
+// count_work_kernel (round 4; diagnostic, never part of a placement): what a batch of packed reads asks of the database -- k-mers
+// probed (sk.getMerCount() per read, AmbigSequenceKnife.java:191), k-mers with a row (hash.getPairsOfTopPosition2(word) != null,
+// PlacementProcess.java:705-707) and the (branch, score) pairs of those rows (the loop of :719-735).  Reads the placement kernels skip
+// (BAD_CHAR / TOO_LONG, shorter than k) or leave to place_ascii_kernel (AMBIGUOUS) count nothing.  One wave per read, a lane per
+// k-mer; a row's true length = its padded length minus the padding that trails it (any image layout: load_entry).
+// ------------------------------------------------------------------------------------------------
+template <int BITS, int TM>
+__global__ void __launch_bounds__(256) count_work_kernel(DbView db, const u32 *packed, u32 wpr, const u32 *lens, u32 fixed_len, const u32 *flags_in,
+                                                         u64 n_reads, unsigned long long *out3) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave_global = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, wave_count = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u32 k = db.k;
+    unsigned long long probed = 0, hits = 0, entries = 0;  // (per lane; summed over the wave at the end)
+    for (u64 r = wave_global; r < n_reads; r += wave_count) {
+        u32 R = lens ? lens[r] : fixed_len;
+        const u32 cap_syms = (wpr * 32u) / BITS;
+        R = R < cap_syms ? R : cap_syms;
+        const u32 fin = flags_in ? flags_in[r] : 0u;
+        const bool skip = (fin & (RK_FLAG_BAD_CHAR | RK_FLAG_TOO_LONG | RK_FLAG_AMBIGUOUS)) != 0 || R < k;
+        const u32 Q = skip ? 0u : R - k + 1;
+        const u32 *rec = packed + r * wpr;
+        for (u32 j0 = 0; j0 < Q; j0 += 64) {
+            const u32 j = j0 + lane;
+            if (j >= Q) continue;
+            probed++;
+            const u64 desc = lookup_desc<BITS, TM>(db, extract_code<BITS>(rec, wpr, j, k));
+            u32 len = (u32)desc & DESC_LEN_MASK;
+            if (!len) continue;
+            hits++;
+            while (len) {  // padding only ever trails a row
+                u32 br;
+                float sc;
+                load_entry(db, desc, len - 1, br, sc);
+                if (br != 0xFFFFu) break;
+                len--;
+            }
+            entries += len;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        probed += __shfl_down(probed, o, 64);
+        hits += __shfl_down(hits, o, 64);
+        entries += __shfl_down(entries, o, 64);
+    }
+    if (lane == 0) {
+        if (probed) atomicAdd(&out3[0], probed);
+        if (hits) atomicAdd(&out3[1], hits);
+        if (entries) atomicAdd(&out3[2], entries);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pack kernel: ASCII -> packed records + lens + flags (AmbigSequenceKnife.java:103-130 char -> state)
 // one thread per output word
 // ------------------------------------------------------------------------------------------------

@@ -326,6 +326,21 @@ class PlacementProcess:
                                                     C.byref(res), C.c_void_p(st)))
         return out
 
+    def count_work(self, packed, fixed_len=0, lens=None, flags_in=None, stream=None):
+        """k-mers probed / k-mers with a row / row entries walked for a batch of packed reads (rk_count_work_device: a kernel of its own,
+        the placement kernels carry no counters) -> dict"""
+        import torch
+        n, wpr = packed.shape
+        dev = packed.device
+        out = torch.empty(3, dtype=torch.int64, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        dp = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.rk_count_work_device(self.db.handle, n, packed.data_ptr(), wpr, dp(lens), fixed_len, dp(flags_in), out.data_ptr(), C.c_void_p(st)))
+        if stream is not None:
+            torch.cuda.synchronize(dev)
+        probed, hit, entries = (int(x) for x in out.tolist())
+        return {"kmers_probed": probed, "kmers_hit": hit, "entries": entries}
+
     def pack_reads(self, seq_ascii, seq_off, max_len, stream=None):
         import torch
         n = seq_off.shape[0] - 1
