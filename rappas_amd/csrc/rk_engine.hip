@@ -1699,7 +1699,7 @@ static int launch_ascii_v(const rk_db *db, PlaceArgs args, AmbArgs m, hipStream_
     // for the list and a minimal Samb/Camb window (then large trees take several ambiguity passes over the alternatives);
     // beyond that (about 39 000 branches) S itself becomes a window of the tree and the read is walked once per window.
     const uint32_t nb = db->info.n_branches;
-    const size_t list_bytes = (size_t)ASCII_LIST_CAP * 8;
+    const size_t list_bytes = (size_t)ASCII_LIST_CAP * 8 + ASCII_TABLE_BYTES;  // (+ the alphabet's tables, behind Camb)
     uint32_t s_win = nb;
     size_t chunk;
     const bool force_windows = db->indexed && rk_knob("RK_WG_PASSES") && atoi(rk_knob("RK_WG_PASSES")) > 1;  // same test knob
@@ -1725,7 +1725,7 @@ static int launch_ascii_v(const rk_db *db, PlaceArgs args, AmbArgs m, hipStream_
     if (chunk == 0 || args.s_stride == 0) return fail(RK_ERR_INVALID, "internal: ambiguity kernel launched without a score-vector geometry");
     m.amb_chunk = (uint32_t)chunk;
     m.s_win = s_win;
-    const size_t lds = (size_t)args.s_stride * 4 + list_bytes + 8 * chunk;
+    const size_t lds = (size_t)args.s_stride * 4 + list_bytes + 8 * chunk;  // S | list | Samb | Camb | tables
     const uint64_t groups = (args.n_reads + 63) / 64;
     uint64_t waves_cu = db->lds_per_cu / lds;
     if (waves_cu > 32) waves_cu = 32;

@@ -3275,6 +3275,7 @@ __global__ void __launch_bounds__(1024) place_wg_kernel(PlaceArgs a) {
 // A1/A2/A7: AmbigSequenceKnife.java:98-272, PlacementProcess.java:1129-1236.
 // ------------------------------------------------------------------------------------------------
 constexpr int ASCII_LIST_CAP = 160;
+constexpr int ASCII_TABLE_BYTES = 640;  // the alphabet's tables in the LDS: [320] alternatives | [16] their counts | [256] character -> state / class
 constexpr int RK_ASCII_RING = 8;
 
 struct AmbArgs {
@@ -3504,7 +3505,7 @@ __device__ __forceinline__ void amb_position(const PlaceArgs &a, const AmbArgs &
 // looked up together and their hit rows go through the same ordered row cursor / register ring as in the packed
 // kernel; an ambiguous position first flushes the pending rows (k-mer order!) and is then handled on its own.
 template <int BITS, int TM, bool SOA>
-__global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m) {
+__global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m_in) {
     extern __shared__ u32 lds[];
     const u32 lane = threadIdx.x & 63;
     const u32 nb_tree = a.db.n_branches;
@@ -3512,9 +3513,9 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     // S covers the branches [s_lo, s_lo + s_win) of the tree: the whole tree in one pass over the read, or -- trees beyond the
     // LDS (the reference accepts ids up to 65 534) -- one pass per window, each leaving its K best for a final merge.
     // Samb/Camb cover `chunk` branches of that window per ambiguity pass.
-    const u32 s_win = m.s_win < nb_tree ? m.s_win : nb_tree;
+    const u32 s_win = m_in.s_win < nb_tree ? m_in.s_win : nb_tree;
     const u32 n_win = (nb_tree + s_win - 1) / s_win;
-    const u32 chunk = m.amb_chunk;
+    const u32 chunk = m_in.amb_chunk;
     u64 *clist = (u64 *)(lds + a.s_stride);  // ASCII_LIST_CAP slots: hit list, then candidate list of select_topk
     float *Samb = (float *)(lds + a.s_stride + 2 * ASCII_LIST_CAP);
     u32 *Camb = lds + a.s_stride + 2 * ASCII_LIST_CAP + chunk;
@@ -3526,6 +3527,16 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
     const __amdgpu_buffer_rsrc_t rows_rs = rows_resource(a.db);
     for (u32 i = lane; i < a.s_stride; i += 64) S[i] = S_UNTOUCHED;
     for (u32 i = lane; i < chunk; i += 64) { Samb[i] = 0.0f; Camb[i] = 0; }
+    // the alternatives of every ambiguity class ([16][20] states + [16] counts, contiguous in the alphabet block) in the LDS: an
+    // ambiguous k-mer looked them up in global memory, one dependent load after the other, ten k-mers per ambiguity code (round 4)
+    unsigned char *alt_l = (unsigned char *)(lds + a.s_stride + 2 * ASCII_LIST_CAP + 2 * chunk);  // [ASCII_TABLE_BYTES] behind Camb (launch_ascii_v)
+    for (u32 i = lane; i < 320u; i += 64) alt_l[i] = m_in.alt_table[i];
+    if (lane < 16u) alt_l[320 + lane] = m_in.alt_count[lane];
+    for (u32 i = lane; i < 256u; i += 64) alt_l[336 + i] = m_in.char_table[i];  // (the character table too: a block's decode is two dependent loads otherwise)
+    AmbArgs m = m_in;
+    m.alt_table = alt_l;
+    m.alt_count = alt_l + 320;
+    m.char_table = alt_l + 336;
     wave_lds_fence();
 #ifdef RK_STAMPS
     unsigned long long st_[16] = {0}, t_ = rk_now();
@@ -3596,6 +3607,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     const bool inr = j < Q;
                     u64 code = 0;      // ambiguous positions contribute state 0
                     u32 ambmask = 0;   // bit i <=> window position i is ambiguous
+                    u32 cls_lo = 0, cls_hi = 0;  // ambiguity class at the first / the last ambiguous position of the window
                     {
                         // every lane decodes two characters of the batch's 64 + k - 1 (its own position and, for the first k - 1
                         // lanes, the one 64 further on); a k-mer's other characters come from the neighbouring lanes
@@ -3608,6 +3620,8 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                             const u32 got = (u32)__shfl((int)pair, (int)(src & 63u), 64);
                             const u32 c = (src < 64u ? got : got >> 8) & 0xFFu;
                             code |= place_bits((c & 0x80) ? 0u : c, BITS * i);
+                            cls_lo = ((c & 0x80) && ambmask == 0) ? (c & 0x7Fu) : cls_lo;
+                            cls_hi = (c & 0x80) ? (c & 0x7Fu) : cls_hi;
                             ambmask |= ((c >> 7) & 1u) << i;
                         }
                         if (!inr) { code = 0; ambmask = 0; }
@@ -3622,7 +3636,7 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                     bool pre_ok = false;
                     if (one_amb) {
                         const u32 p = __builtin_ctz(ambmask);
-                        const u32 cls = m.char_table[s[j + p]] & 0x7F;
+                        const u32 cls = cls_lo;
                         const u32 W = m.alt_count[cls];
                         if (W <= 4) {
                             pre_ok = true;
@@ -3654,9 +3668,9 @@ __global__ void __launch_bounds__(64) place_ascii_kernel(PlaceArgs a, AmbArgs m)
                         const u32 n_amb = (u32)__builtin_popcount(maskA);
                         if (n_amb >= 1 && n_amb <= m.max_amb && n_amb <= 2 && m.amb_mode != RK_AMB_SKIP) {
                             const u32 p = __builtin_ctz(maskA);
-                            const u32 cls = m.char_table[s[j0 + na + p]] & 0x7F;
+                            const u32 cls = (u32)__builtin_amdgcn_readlane((int)cls_lo, (int)na);
                             const u32 p2 = 31u - (u32)__builtin_clz(maskA);  // the second ambiguous position (DNA k >= 16), == p otherwise
-                            const u32 cls2 = n_amb == 2 ? (u32)(m.char_table[s[j0 + na + p2]] & 0x7F) : 0xFFu;
+                            const u32 cls2 = n_amb == 2 ? (u32)__builtin_amdgcn_readlane((int)cls_hi, (int)na) : 0xFFu;
                             const bool have_pre = n_amb == 1 && __builtin_amdgcn_readlane((int)pre_ok, (int)na) != 0;
                             u64 pre[4];
 #pragma unroll

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RK_LIB"] = os.path.join(ROOT, "rappas_amd", "variants", "librk_stamps.so")
+os.environ["RK_LIB"] = os.environ.get("RK_STAMPS_LIB") or os.path.join(ROOT, "rappas_amd", "variants", "librk_stamps.so")
 import numpy as np, torch
 import rappas_amd as ra
 from rappas_amd import synth
