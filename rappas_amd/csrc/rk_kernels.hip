@@ -2680,11 +2680,21 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                         h[p] = mask_select((h[p] + hop4) & (NS * 4u - 4u), h[p], ok);
                     }
                 } while (pending != 0ull);
+                // the stamps and the values of the step's slots in ONE round trip: the values are what the step needs when no two of its
+                // units meet in a branch (the usual case), and are read again unit by unit otherwise
+                // (value of slot s: VOFF words behind its key; the lane's own word serves both and stays 0)
                 u64 clash = 0ull;
+                u32 at[NPL];
+                float v[NPL];
                 {
                     u32 prev[NPL];
 #pragma unroll
                     for (int p = 0; p < NPL; p++) prev[p] = atomicMax((u32 *)((unsigned char *)lds + h[p]), mask_select(0u, key[p] | (stamp << KEY_BITS), act[p]));
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        at[p] = mask_select(own, h[p] + VOFF * 4u, act[p]);
+                        v[p] = __uint_as_float(*(u32 *)((unsigned char *)lds + at[p]));
+                    }
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
                         n_keys += (u32)__builtin_popcountll(fresh[p] & act[p]);
@@ -2694,15 +2704,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                 float d[NPL];
 #pragma unroll
                 for (int p = 0; p < NPL; p++) d[p] = scv[p] - T;
-                // (value of slot s: VOFF words behind its key; the lane's own word serves both and stays 0)
                 if (clash == 0ull) {
-                    u32 at[NPL];
-                    float v[NPL];
-#pragma unroll
-                    for (int p = 0; p < NPL; p++) {
-                        at[p] = mask_select(own, h[p] + VOFF * 4u, act[p]);
-                        v[p] = __uint_as_float(*(u32 *)((unsigned char *)lds + at[p]));
-                    }
 #pragma unroll
                     for (int p = 0; p < NPL; p++) *(u32 *)((unsigned char *)lds + at[p]) = mask_select(0u, __float_as_uint(v[p] + d[p]), act[p]);
                 } else {  // the step's units one after the other: k-mer order per branch
