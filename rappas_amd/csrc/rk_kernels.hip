@@ -696,6 +696,19 @@ __device__ __forceinline__ u32 mask_select(u32 if_clear, u32 if_set, u64 m) {
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
 }
+// A returning LDS compare-and-swap whose result the CALLER waits for (lds_cas_wait over all results before their first use), so that
+// several are in flight at once.  at = byte offset in the workgroup's LDS (kernels without static LDS: the dynamic block starts at 0).
+__device__ __forceinline__ u32 lds_cas_issue(u32 at, u32 expect, u32 put) {
+    u32 r;
+    asm volatile("ds_cmpst_rtn_b32 %0, %1, %2, %3" : "=v"(r) : "v"(at), "v"(expect), "v"(put) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_cas_wait(u32 (&r)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(r[i]));  // (the results are defined from here on)
+}
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {  // wave-uniform maximum: four DPP row steps, then the four rows' results through SGPRs
     v = max(v, row_ror32<8>(v));
     v = max(v, row_ror32<4>(v));
@@ -2563,6 +2576,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
     u32 *vals = lds + NS + 64;
     u32 *items = lds + 2 * NS + 64;
     constexpr u32 VOFF = NS + 64;  // lds[VOFF + slot] = the slot's value; lds[NS + lane] = the lane's own word, for key and value operations alike
+    if (__builtin_amdgcn_groupstaticsize() != 0u) __builtin_trap();  // (lds_cas_issue takes offsets from the start of the LDS)
     const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 gi = lane >> 4, li8 = (lane & 15u) * 8u;
@@ -2668,9 +2682,12 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                     st_[14] += 1;
 #endif
                     hop4 += 4u;
+                    // (inline assembly with ONE wait behind the step's compare-and-swaps: hipcc gave each its own s_waitcnt, four LDS
+                    //  round trips a round where one does)
                     u32 old[NPL];
 #pragma unroll
-                    for (int p = 0; p < NPL; p++) old[p] = atomicCAS((u32 *)((unsigned char *)lds + h[p]), 0u, key[p]);  // (the lane's own word: compares 0 with 0)
+                    for (int p = 0; p < NPL; p++) old[p] = lds_cas_issue(h[p], 0u, key[p]);  // (the lane's own word: compares 0 with 0)
+                    lds_cas_wait(old);
                     pending = 0ull;
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
