@@ -651,8 +651,11 @@ def main():
     H_mean = H_total / n_reads
     B = math.ceil(rlen * bits / 8) + Q * 8 + H_mean * 6 + (2 + K * 14)
     # the engine's own count of the same quantities (rk_count_work_device: a kernel of its own) next to the torch count above
-    work = pp.count_work(packed, fixed_len=rlen)
-    work["equals_independent_count"] = bool(work["entries"] == H_total and work["kmers_hit"] == hit_kmers and work["kmers_probed"] == n_reads * Q)
+    try:
+        work = pp.count_work(packed, fixed_len=rlen)
+        work["equals_independent_count"] = bool(work["entries"] == H_total and work["kmers_hit"] == hit_kmers and work["kmers_probed"] == n_reads * Q)
+    except AttributeError:  # (RK_LIB pointing at a build older than the entry point)
+        work = None
 
     for _ in range(a.warmup):
         step()

@@ -150,8 +150,8 @@ def _open(path, mode):
         pass
     lib = C.CDLL(path, mode=mode)
     for name, (res, args) in EXPORTS.items():
-        if name.startswith("rk_buil") and os.environ.get("RK_LIB") and not hasattr(lib, name):
-            continue  # developer timing builds (scripts/) compile the placement unit only
+        if os.environ.get("RK_LIB") and not hasattr(lib, name):
+            continue  # developer timing builds (scripts/) compile the placement unit only, or an earlier revision of it
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
