@@ -2675,15 +2675,18 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
 #endif
                 // Every lane that is still looking has failed in every round so far, so the distance of its next hop -- triangular
                 // probing: 1, 2, 3 ... slots, every slot is visited -- is the round's number: one scalar for the wave.
+                // Two rounds with all of the step's 64 * NPL entries; the few that are still looking after those (a table at 0.33 mean /
+                // 0.65 final load: one in twenty) go on ONE per lane -- a round of the longest probe sequence then costs a quarter
+                // of the instructions and a quarter of the compare-and-swaps.  (inline assembly with one wait behind a round's
+                // compare-and-swaps: hipcc gave each its own s_waitcnt)
                 u32 hop4 = 0;
-                u64 pending;
-                do {
+                u64 pend[NPL], pending = 0ull;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
 #ifdef RK_STAMPS
                     st_[14] += 1;
 #endif
                     hop4 += 4u;
-                    // (inline assembly with ONE wait behind the step's compare-and-swaps: hipcc gave each its own s_waitcnt, four LDS
-                    //  round trips a round where one does)
                     u32 old[NPL];
 #pragma unroll
                     for (int p = 0; p < NPL; p++) old[p] = lds_cas_issue(h[p], 0u, key[p]);  // (the lane's own word: compares 0 with 0)
@@ -2693,10 +2696,48 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                     for (int p = 0; p < NPL; p++) {
                         const u64 mine = mask_eq0(old[p]), ok = mine | mask_eq_lo16(old[p], key[p]);
                         fresh[p] |= mine;
+                        pend[p] = ~ok;
                         pending |= ~ok;
                         h[p] = mask_select((h[p] + hop4) & (NS * 4u - 4u), h[p], ok);
                     }
-                } while (pending != 0ull);
+                    if (pending == 0ull) break;
+                }
+                while (pending != 0ull) {
+                    // every lane's first entry that is still looking (lanes without one: their own word).  All of them have failed twice:
+                    // the next hop is three slots, for those of a later turn of this loop too
+                    u64 taken = 0ull, sel[NPL];
+                    u32 km = 0u, hm = own;
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        sel[p] = pend[p] & ~taken;
+                        taken |= pend[p];
+                        km = mask_select(km, key[p], sel[p]);
+                        hm = mask_select(hm, h[p], sel[p]);
+                    }
+                    u32 hopm = 8u;
+                    u64 fm = 0ull, pm;
+                    do {
+#ifdef RK_STAMPS
+                        st_[9] += 1;
+#endif
+                        hopm += 4u;
+                        u32 oldm[1];
+                        oldm[0] = lds_cas_issue(hm, 0u, km);
+                        lds_cas_wait(oldm);
+                        const u64 mine = mask_eq0(oldm[0]), ok = mine | mask_eq_lo16(oldm[0], km);
+                        fm |= mine;
+                        pm = ~ok;
+                        hm = mask_select((hm + hopm) & (NS * 4u - 4u), hm, ok);
+                    } while (pm != 0ull);
+                    pending = 0ull;
+#pragma unroll
+                    for (int p = 0; p < NPL; p++) {
+                        h[p] = mask_select(h[p], hm, sel[p]);
+                        fresh[p] |= fm & sel[p];
+                        pend[p] &= ~sel[p];
+                        pending |= pend[p];
+                    }
+                }
                 // the stamps and the values of the step's slots in ONE round trip: the values are what the step needs when no two of its
                 // units meet in a branch (the usual case), and are read again unit by unit otherwise
                 // (value of slot s: VOFF words behind its key; the lane's own word serves both and stays 0)
