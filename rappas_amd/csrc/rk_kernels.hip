@@ -691,6 +691,11 @@ __device__ __forceinline__ u64 mask_eq_lo16(u32 a, u32 b) {  // the low 16 bits 
     asm("v_cmp_eq_u16_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
     return m;
 }
+__device__ __forceinline__ u64 mask_ge(u32 a, u32 b) {  // a >= b (unsigned), b wave-uniform
+    u64 m;
+    asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
+    return m;
+}
 __device__ __forceinline__ u32 mask_select(u32 if_clear, u32 if_set, u64 m) {
     u32 r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
@@ -2641,7 +2646,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
             RK_STAMP(0);  // read setup + table reset
 
             bool over = false;  // (wave-uniform) the read does not fit: table, list or candidates
-            u32 n_keys = 0;     // (wave-uniform) keys in the table
+            u32 n_keys = 0;     // (wave-uniform) an upper bound of the keys in the table: the entries applied so far (recounted when it matters)
             u32 stamp = 1;      // (wave-uniform) number of the next step
             int cnt = 0;        // items waiting in the list
 
@@ -2655,20 +2660,34 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                 // as wave masks in SGPRs and combined there (hipcc turns a bool that feeds both a select and a ballot into a 0 / 1
                 // register and a second compare): a round is 6 vector instructions an entry.
                 u32 key[NPL], h[NPL];
-                u64 act[NPL], fresh[NPL];
+                u64 act[NPL];
                 const u32 own = (NS + lane) * 4u;
 #pragma unroll
                 for (int p = 0; p < NPL; p++) {
                     key[p] = sbv[p] >> 2;  // (branch + 1; 0 = padding of a unit, a filler item)
                     act[p] = ~mask_eq0(key[p]);
                     h[p] = mask_select(own, ((key[p] * 0x9E3779B1u) >> (32 - LOGS)) << 2, act[p]);
-                    fresh[p] = 0ull;
                 }
                 {   // the table takes this step only if it cannot fill up: keys so far + the step's entries (each may be a new key)
                     u32 n_act = 0;
 #pragma unroll
                     for (int p = 0; p < NPL; p++) n_act += (u32)__builtin_popcountll(act[p]);
-                    if (n_keys + n_act > key_limit) { over = true; return; }
+                    if (n_keys + n_act > key_limit) {
+                        // the bound counts every entry as a key of its own: before a read is given up its table is counted (uniform
+                        // reads: entries ~ keys, this never runs; clade-shaped ones have 1 800 entries on 500 keys and come here near their end)
+                        const uint4 *kk = (const uint4 *)keys;
+                        u32 mine_n = 0;
+#pragma unroll 2
+                        for (u32 i = 0; i < NS / 4u / 64u; i++) {
+                            const uint4 kq = kk[i * 64u + lane];
+                            mine_n += (kq.x ? 1u : 0u) + (kq.y ? 1u : 0u) + (kq.z ? 1u : 0u) + (kq.w ? 1u : 0u);
+                        }
+                        u32 tot_n;
+                        (void)wave_scan(mine_n, tot_n);
+                        n_keys = tot_n;
+                        if (n_keys + n_act > key_limit) { over = true; return; }
+                    }
+                    n_keys += n_act;
                 }
 #ifdef RK_STAMPS
                 st_[15] += 1;
@@ -2695,7 +2714,6 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
                         const u64 mine = mask_eq0(old[p]), ok = mine | mask_eq_lo16(old[p], key[p]);
-                        fresh[p] |= mine;
                         pend[p] = ~ok;
                         pending |= ~ok;
                         h[p] = mask_select((h[p] + hop4) & (NS * 4u - 4u), h[p], ok);
@@ -2715,7 +2733,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                         hm = mask_select(hm, h[p], sel[p]);
                     }
                     u32 hopm = 8u;
-                    u64 fm = 0ull, pm;
+                    u64 pm;
                     do {
 #ifdef RK_STAMPS
                         st_[9] += 1;
@@ -2725,7 +2743,6 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                         oldm[0] = lds_cas_issue(hm, 0u, km);
                         lds_cas_wait(oldm);
                         const u64 mine = mask_eq0(oldm[0]), ok = mine | mask_eq_lo16(oldm[0], km);
-                        fm |= mine;
                         pm = ~ok;
                         hm = mask_select((hm + hopm) & (NS * 4u - 4u), hm, ok);
                     } while (pm != 0ull);
@@ -2733,7 +2750,6 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
                         h[p] = mask_select(h[p], hm, sel[p]);
-                        fresh[p] |= fm & sel[p];
                         pend[p] &= ~sel[p];
                         pending |= pend[p];
                     }
@@ -2755,8 +2771,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
                     }
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
-                        n_keys += (u32)__builtin_popcountll(fresh[p] & act[p]);
-                        clash |= mask_eq0((prev[p] >> KEY_BITS) ^ stamp);  // another unit of this step updates the same branch
+                        clash |= mask_ge(prev[p], stamp << KEY_BITS);  // the step's own stamp (none is larger): another of its units updates the same branch
                     }
                 }
                 float d[NPL];
