@@ -1457,16 +1457,27 @@ constexpr uint32_t RK_HASH_LOG_SLOTS = RK_HASH_LOGS, RK_HASH_MAIN_CAP = 320;
 #define RK_HASH_KEY_SLACK 48u  // slots kept free: a read's table takes NS - this many keys (the kernel counts a step's entries before it takes the step)
 #endif
 // From this many branches on place_hash64_kernel is ahead of place_packed16s_kernel, whose cost grows with the windows a tree is cut
-// into (profiles/r04_hash_crossover.txt; C2-like rows, Mreads/s hash / sorted-stream: 28 001 branches 88 / 92, 39 999: 87 / 69,
-// 65 535: 87 / 34; clade-shaped reads 81 / 111 at 28 001, 80 / 89 at 39 999, 80 / 45 at 65 535: uniform reads cross at ~30 000,
-// clade-shaped ones at ~45 000, the rule sits between)
+// into (profiles/r04_hash_crossover.txt and DESIGN.md 4.1d; C2-like rows, Mreads/s hash / sorted-stream: uniform reads 19 999 branches
+// 94 / 108, 28 001: 95 / 95, 39 999: 95 / 71, 65 535: 94 / 35; clade-shaped reads 82 / 119 at 28 001, 81 / 95 at 39 999, 82 / 47 at
+// 65 535; 92 / 81 at 50 001, 84 / 81 at 55 001, 48 / 81 at 60 001).  Uniform reads cross at ~28 000 branches, clade-shaped ones at ~56 000: in between BOTH kernels are launched and the
+// batch's shape -- what the re-tiling pre-pass found, on the device -- says which of them runs (PlaceArgs::only_if); a batch without
+// the pre-pass (fewer than 32 768 reads) goes by the single rule in the middle.
 #ifndef RK_HASH_MIN_BRANCHES
 #define RK_HASH_MIN_BRANCHES 36000u
 #endif
-static bool hash_tree(const rk_db *db) {  // images whose tiles go to place_hash64_kernel first
+#ifndef RK_HASH_MIN_BRANCHES_UNIFORM
+#define RK_HASH_MIN_BRANCHES_UNIFORM 28000u
+#endif
+#ifndef RK_HASH_MIN_BRANCHES_CLADE
+#define RK_HASH_MIN_BRANCHES_CLADE 56000u
+#endif
+static bool hash_capable(const rk_db *db) {  // images whose tiles can go to place_hash64_kernel first
     if (rk_knob("RK_NO_HASH") || rk_knob("RK_NO_WSTREAM") || db->info.rows_bytes >= ROWS_FIT32_LIMIT) return false;
-    if (rk_knob("RK_HASH_ALWAYS")) return true;
-    return db->wp.stream && db->info.n_branches > RK_HASH_MIN_BRANCHES;
+    return rk_knob("RK_HASH_ALWAYS") || db->wp.stream;
+}
+static bool hash_tree(const rk_db *db) {  // ... by the single rule
+    if (!hash_capable(db)) return false;
+    return rk_knob("RK_HASH_ALWAYS") || db->info.n_branches > RK_HASH_MIN_BRANCHES;
 }
 static uint32_t hash_key_limit() {
     uint32_t slack = RK_HASH_KEY_SLACK;
@@ -1490,13 +1501,21 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     const bool one_batch = a.lens != nullptr || a.fixed_len < db->info.k || a.fixed_len - db->info.k + 1 <= probe_cap;
     // place_hash64_kernel first: images of short rows (the rule place_packed16s_kernel had), reads whose distinct branches -- at most
     // their entries, ~9.3 a unit with C2-like rows -- fit the table (profiles/r04_lsize_hist.txt)
-    const bool hash_first = !no_stream && hash_tree(db) && (est_units * 9.3 <= 0.8 * hash_key_limit() || rk_knob("RK_HASH_ALWAYS"));
-    const bool sorted_first = !hash_first && a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
+    const bool hash_fits = !no_stream && hash_capable(db) && (est_units * 9.3 <= 0.8 * hash_key_limit() || rk_knob("RK_HASH_ALWAYS"));
+    const bool sorted_fits = a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
     TileOrder order;
-    if (int rc = order.prepare(db, a, stream, hash_first || sorted_first)) return rc;
+    if (int rc = order.prepare(db, a, stream, hash_fits || sorted_fits)) return rc;
     const bool first_ok = a.tile_marks != nullptr;  // (no scratch to be had for the marks: place_packed16w_kernel alone)
+    // which of the two goes first: by the tree's size; between the two crossing points, and when the batch went through the re-tiling
+    // pre-pass (a.perm: its verdict on the batch's shape is on the device), both are launched and one of them returns at once
+    const uint32_t nb_tree = db->info.n_branches;
+    const bool forced = rk_knob("RK_HASH_ALWAYS") != nullptr;
+    const bool by_shape = hash_fits && sorted_fits && !forced && a.perm != nullptr && nb_tree > RK_HASH_MIN_BRANCHES_UNIFORM && nb_tree <= RK_HASH_MIN_BRANCHES_CLADE;
+    const bool hash_first = hash_fits && (forced || by_shape || nb_tree > (a.perm != nullptr ? RK_HASH_MIN_BRANCHES_CLADE : RK_HASH_MIN_BRANCHES) || (!sorted_fits && hash_tree(db)));
+    const bool sorted_first = sorted_fits && (by_shape || !hash_first);
     if (hash_first && first_ok) {
         PlaceArgs b = a;
+        b.only_if = by_shape ? 1u : 0u;  // (uniform reads: the batch kept its order)
         b.s_stride = 1u << RK_HASH_LOG_SLOTS; b.main_cap = RK_HASH_MAIN_CAP; b.work_cap = hash_key_limit(); b.list_cap = 0; b.only_marked = 0;
         const size_t lds_wave = (size_t)(2 * b.s_stride + 64 + b.main_cap) * 4;
         auto launch = [&](auto kern) -> int {
@@ -1519,6 +1538,7 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
         //      its window segments ----
         PlaceArgs b = a;
+        b.only_if = by_shape ? 2u : 0u;  // (reads of a clade: the batch was re-tiled)
         const uint32_t work_min = 96u;  // scratch of the second pass: 48 candidate keys
         // ring of row loads: eight deep, a window's segment padded to half turns of it (four deep it left the stream waiting
         // on HBM: ~280 cycles a step; segments padded to whole turns of eight made the largest trees' lists half filler)
@@ -1765,7 +1785,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     if (!db) return "";
     Geometry g;
     rk_db *m = const_cast<rk_db *>(db);
-    char buf[200];
+    char buf[320];
     if (db->indexed && db->lanes_per_read == 0) {
         WgGeometry wg;
         if (choose_wg_geometry(db, wg, 7) != RK_OK) return "";
@@ -1776,9 +1796,13 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
-        if (hash_tree(db) && (rk_knob("RK_HASH_ALWAYS") || 141.0 * db->wp.units_per_code * 9.3 <= 0.8 * hash_key_limit()))
-            snprintf(buf, sizeof(buf), "place_hash64_kernel<BITS=%u,U=%d,NPL=%d,PU=%d,LOGS=%u> %u slots, <= %u keys a read (+ place_packed16w_kernel for the tiles it hands over; windows=%u x %u branches)",
-                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, RK_HASH_LOG_SLOTS, 1u << RK_HASH_LOG_SLOTS, hash_key_limit(), db->wp.n_win, db->wp.W);
+        const bool hash_fits = hash_capable(db) && (rk_knob("RK_HASH_ALWAYS") || 141.0 * db->wp.units_per_code * 9.3 <= 0.8 * hash_key_limit());
+        const bool band = hash_fits && !rk_knob("RK_HASH_ALWAYS") && db->wp.stream && db->info.n_branches > RK_HASH_MIN_BRANCHES_UNIFORM && db->info.n_branches <= RK_HASH_MIN_BRANCHES_CLADE;
+        if (hash_fits && (band || hash_tree(db)))
+            snprintf(buf, sizeof(buf), "place_hash64_kernel<BITS=%u,U=%d,NPL=%d,PU=%d,LOGS=%u> %u slots, <= %u keys a read%s (+ place_packed16w_kernel for the tiles it hands over; windows=%u x %u branches)",
+                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, RK_HASH_LOG_SLOTS, 1u << RK_HASH_LOG_SLOTS, hash_key_limit(),
+                     band ? (db->info.n_branches > RK_HASH_MIN_BRANCHES ? " | place_packed16s_kernel for batches of clade-shaped reads" : " for batches of uniform reads of 32 768 or more | place_packed16s_kernel otherwise") : "",
+                     db->wp.n_win, db->wp.W);
         else if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
             snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
                      db->info.bits_per_symbol, db->info.bits_per_symbol == 5 ? 7 : 9, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);

@@ -2082,6 +2082,7 @@ template <int BITS, int U, int PU, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16s_kernel(PlaceArgs a) {  // (amino acids: 264 registers left to itself, one wave per SIMD)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2, TURNS = 8;
     extern __shared__ u32 lds[];
+    if (a.only_if && a.perm && ((*a.keep_order != 0u) != (a.only_if == 1u))) return;  // (place_hash64_kernel takes this batch)
     const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
@@ -2582,6 +2583,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
     u32 *items = lds + 2 * NS + 64;
     constexpr u32 VOFF = NS + 64;  // lds[VOFF + slot] = the slot's value; lds[NS + lane] = the lane's own word, for key and value operations alike
     if (__builtin_amdgcn_groupstaticsize() != 0u) __builtin_trap();  // (lds_cas_issue takes offsets from the start of the LDS)
+    if (a.only_if && a.perm && ((*a.keep_order != 0u) != (a.only_if == 1u))) return;  // (the other first kernel takes this batch)
     const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 gi = lane >> 4, li8 = (lane & 15u) * 8u;

@@ -31,8 +31,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.exit(0)
 for nb in [int(x) for x in sys.argv[1:]] or [12001, 19999, 28001, 39999, 65535]:
     for shape in ("uniform", "clade"):
-        for knob in ("RK_NO_HASH", "RK_HASH_ALWAYS"):
+        for knob in ("RK_NO_HASH", "RK_HASH_ALWAYS", "(the engine's choice)"):
             env = dict(os.environ, RK_LIB=os.environ.get("RK_VARIANT_LIB") or os.path.join(ROOT, "rappas_amd", "librappas_place_dev.so"))
-            env[knob] = "1"
+            if knob.startswith("RK_"):
+                env[knob] = "1"
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(nb), shape], env=env, capture_output=True, text=True)
-            print(f"n_branches={nb:6d} {shape:8s} {knob:15s} {(r.stdout.strip() or r.stderr.strip()[-200:])}", flush=True)
+            print(f"n_branches={nb:6d} {shape:8s} {knob:21s} {(r.stdout.strip() or r.stderr.strip()[-200:])}", flush=True)

@@ -918,6 +918,26 @@ def test_hash_kernel_units_of_a_step_that_meet_in_a_branch(n_branches, monkeypat
         assert st["placed"] > 1900
 
 
+@pytest.mark.parametrize("n_branches", [30001, 52001])
+def test_first_kernel_by_the_shape_of_the_batch(n_branches, monkeypatch, dev_lib):
+    """between the two crossing points (28 000 / 56 000 branches) place_hash64_kernel and place_packed16s_kernel are both launched and the
+    verdict of the re-tiling pre-pass on the batch -- uniform reads keep their order, reads of a clade are re-tiled -- says which of
+    them runs: a clade-shaped batch, a uniform one and a mixed one all equal the oracle (the pre-pass switched on for small batches)"""
+    monkeypatch.setenv("RK_RETILE_MIN_READS", "0")
+    sdb, genome = _clade_db(9, n_branches, 6000, seed=n_branches, mean_row=12.0)
+    odb = O.OracleDB.from_synth(sdb)
+    db = ra.PhyloKmerDB.from_synth(sdb)
+    name = db.kernel_name()
+    db.close()
+    assert "place_hash64_kernel" in name and "place_packed16s_kernel" in name, name
+    s1, o1 = synth.make_motif_reads(genome, 2500, 150, seed=5, amb_rate=0.001, var_len=40)
+    s2, o2 = synth.make_reads(4, 2500, 150, seed=6, var_len=60, amb_rate=0.001, bad_rate=0.002)
+    for seq, off in ((s1, o1), (s2, o2), (np.concatenate([s1, s2]), np.concatenate([o1, o2[1:] + o1[-1]]))):
+        for K in (7, 12):
+            _, _, st = run_case(sdb, odb, seq, off, "direct", 0, "mean", keepAtMost=K)
+            assert st["placed"] > 1000
+
+
 @pytest.mark.parametrize("kernel", ["hash", "sorted"])
 @pytest.mark.parametrize("seed", range(6 + _EXTRA_SEEDS))
 def test_short_row_kernels_of_big_trees_with_scores_from_a_handful_of_values(seed, kernel, request, monkeypatch):
