@@ -325,16 +325,17 @@ def make_motif_reads(genome, n_reads, length, seed=1, amb_rate=0.0, var_len=0):
     return np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy(), off
 
 
-def make_clade_db(k=10, n_branches=999, genome_len=700_000, mean_row=12.7, seed=5, omega=1.5):
+def make_clade_db(k=10, n_branches=999, genome_len=700_000, mean_row=12.7, seed=5, omega=1.5, alphabet=4):
     """Database + genome for reads whose best branches are NEIGHBOURS (a clade: the usual shape of real placements).  The keys are
     the k-mers of a random genome; the rows of one 500-bp stretch cover the same few dozen branches, so the rows of a read cut from
     the genome pile up on one neighbourhood of the tree.  Every k-mer of such a read is present (hit rate 1 against the 0.75 of the
     uniform benchmark reads).  -> (SynthDB, genome states uint64[genome_len])"""
     rng = np.random.default_rng(seed)
-    g = rng.integers(0, 4, size=genome_len).astype(np.uint64)
+    g = rng.integers(0, alphabet, size=genome_len).astype(np.uint64)
     codes = np.zeros(genome_len - k + 1, dtype=np.uint64)
+    bits = 2 if alphabet == 4 else 5
     for i in range(k):
-        codes += g[i:genome_len - k + 1 + i] << np.uint64(2 * i)
+        codes += g[i:genome_len - k + 1 + i] << np.uint64(bits * i)
     key_codes, first = np.unique(codes, return_index=True)
     order = rng.permutation(len(key_codes))
     key_codes, pos = key_codes[order], first[order]
@@ -348,17 +349,17 @@ def make_clade_db(k=10, n_branches=999, genome_len=700_000, mean_row=12.7, seed=
     total = int(off[-1])
     within = np.arange(total, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), lens)
     branch = (np.repeat(b0, lens) + within).astype(np.uint16)
-    thr, thr_log10 = thresholds(omega, 4, k)
+    thr, thr_log10 = thresholds(omega, alphabet, k)
     scores = (thr_log10 * rng.random(total, dtype=np.float32)).astype(np.float32)
-    return SynthDB(4, k, nb, thr, thr_log10, key_codes, off, branch, scores, seed), g
+    return SynthDB(alphabet, k, nb, thr, thr_log10, key_codes, off, branch, scores, seed), g
 
 
-def make_clade_reads(genome, n_reads, length=150, seed=6):
+def make_clade_reads(genome, n_reads, length=150, seed=6, alphabet=4):
     """substrings of the genome of make_clade_db -> (seq uint8 [n * length], off uint64 [n + 1])"""
     rng = np.random.default_rng(seed)
     starts = rng.integers(0, len(genome) - length, size=n_reads)
     idx = (starts[:, None] + np.arange(length)[None, :]).reshape(-1)
-    seq = DNA_LETTERS[genome[idx].astype(np.int64)]
+    seq = (DNA_LETTERS if alphabet == 4 else AA_LETTERS)[genome[idx].astype(np.int64)]
     return np.ascontiguousarray(seq), (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(length))
 
 

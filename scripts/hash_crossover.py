@@ -16,21 +16,34 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         pp = ra.PlacementProcess(db)
         seq, offs = synth.make_clade_reads(g, n, 150)
         packed = torch.from_numpy(pp.pack_reads_host(seq, offs)[0].view(np.int32)).cuda()
+    elif shape == "aa-clade":  # amino acids k = 5, 100-residue reads cut from the "genome" whose k-mers make up the database
+        sdb, g = synth.make_clade_db(k=5, n_branches=nb, alphabet=20)
+        db = ra.PhyloKmerDB.from_synth(sdb)
+        pp = ra.PlacementProcess(db)
+        seq, offs = synth.make_clade_reads(g, n, 100, alphabet=20)
+        packed, _, _ = pp.pack_reads(torch.from_numpy(seq).cuda(), torch.from_numpy(offs.view(np.int64)).cuda(), 100)
+    elif shape == "aa":  # amino acids k = 5, 100-residue reads on C4-like rows
+        db = ra.PhyloKmerDB.from_synth(synth.make_db(20, 5, nb, 786432, 10_000_000, seed=42))
+        pp = ra.PlacementProcess(db)
+        seq, off = synth.make_reads(20, n, 100, seed=1)
+        packed, _, _ = pp.pack_reads(torch.from_numpy(seq).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), 100)
     else:
         db = ra.PhyloKmerDB.from_synth(synth.make_db(4, 10, nb, 786432, 10_000_000, seed=42))
         pp = ra.PlacementProcess(db)
         wpr = db.packed_words(150)
         packed = torch.randint(-2**31, 2**31, (n, wpr), dtype=torch.int64, device="cuda").to(torch.int32)
         packed[:, wpr - 1] &= (1 << (300 - 32 * (wpr - 1))) - 1
-    out = pp.place_packed(packed, fixed_len=150); torch.cuda.synchronize()
+    rl = 100 if shape.startswith("aa") else 150
+    out = pp.place_packed(packed, fixed_len=rl); torch.cuda.synchronize()
     t = time.time()
     for _ in range(3):
-        pp.place_packed(packed, fixed_len=150, out=out)
+        pp.place_packed(packed, fixed_len=rl, out=out)
     torch.cuda.synchronize()
     print(f"{n * 3 / (time.time() - t) / 1e6:8.1f} Mreads/s  [{db.kernel_name()[:34]}]")
     sys.exit(0)
-for nb in [int(x) for x in sys.argv[1:]] or [12001, 19999, 28001, 39999, 65535]:
-    for shape in ("uniform", "clade"):
+shapes = ("aa", "aa-clade") if "aa" in sys.argv[1:] else ("uniform", "clade")
+for nb in [int(x) for x in sys.argv[1:] if x != "aa"] or [12001, 19999, 28001, 39999, 65535]:
+    for shape in shapes:
         for knob in ("RK_NO_HASH", "RK_HASH_ALWAYS", "(the engine's choice)"):
             env = dict(os.environ, RK_LIB=os.environ.get("RK_VARIANT_LIB") or os.path.join(ROOT, "rappas_amd", "librappas_place_dev.so"))
             if knob.startswith("RK_"):
