@@ -1462,34 +1462,37 @@ constexpr uint32_t RK_HASH_LOG_SLOTS = RK_HASH_LOGS, RK_HASH_MAIN_CAP = 320;
 // 65 535; 92 / 81 at 50 001, 84 / 81 at 55 001, 48 / 81 at 60 001).  Uniform reads cross at ~28 000 branches, clade-shaped ones at ~56 000: in between BOTH kernels are launched and the
 // batch's shape -- what the re-tiling pre-pass found, on the device -- says which of them runs (PlaceArgs::only_if); a batch without
 // the pre-pass (fewer than 32 768 reads) goes by the single rule in the middle.
-#ifndef RK_HASH_MIN_BRANCHES
-#define RK_HASH_MIN_BRANCHES 36000u
-#endif
-#ifndef RK_HASH_MIN_BRANCHES_UNIFORM
-#define RK_HASH_MIN_BRANCHES_UNIFORM 28000u
-#endif
 #ifndef RK_HASH_MIN_BRANCHES_CLADE
 #define RK_HASH_MIN_BRANCHES_CLADE 56000u
 #endif
 // amino acids (k = 5, 100 residues, C4-like rows: a quarter of the k-mers present, ~300 entries a read): the hash kernel runs 196 Mreads/s
 // at any size, place_packed16s_kernel 231 / 205 / 177 / 119 / 51 at 9 001 / 12 001 / 15 999 / 33 001 / 65 535 branches -- they cross at
 // ~13 500; reads cut from the sequence the k-mers come from 107 against 198 / 168 / 136 / 65 at 9 001 / 25 001 / 46 001 / 60 001: ~56 000
-// as for DNA (profiles/r04_hash_crossover.txt)
-#ifndef RK_HASH_MIN_BRANCHES_UNIFORM_AA
-#define RK_HASH_MIN_BRANCHES_UNIFORM_AA 13500u
+// as for DNA (profiles/r04_hash_crossover_aa.txt).
+// The hash kernel's cost follows a read's row units, place_packed16s_kernel's the units AND the windows: through the two measured
+// crossings -- 145 units a read (C2, 150 bp) at 28 000 branches, 33 (C4-like, 100 residues) at 13 500 -- the uniform crossing is taken as
+// 130 branches per unit + 9 250 for other row densities and read lengths; batches too small for the pre-pass go by that + 8 000
+// (36 000 for C2-like rows).  -DRK_HASH_MIN_BRANCHES_UNIFORM_FIXED=n replaces the fit by a constant.
+static uint32_t hash_min_uniform(double est_units) {
+#ifdef RK_HASH_MIN_BRANCHES_UNIFORM_FIXED
+    (void)est_units;
+    return RK_HASH_MIN_BRANCHES_UNIFORM_FIXED;
+#else
+    const double nb = 130.0 * est_units + 9250.0;
+    return nb > (double)RK_HASH_MIN_BRANCHES_CLADE ? RK_HASH_MIN_BRANCHES_CLADE : (uint32_t)nb;
 #endif
-#ifndef RK_HASH_MIN_BRANCHES_AA
-#define RK_HASH_MIN_BRANCHES_AA 24000u
-#endif
-static uint32_t hash_min_uniform(const rk_db *db) { return db->info.bits_per_symbol == 5 ? RK_HASH_MIN_BRANCHES_UNIFORM_AA : RK_HASH_MIN_BRANCHES_UNIFORM; }
-static uint32_t hash_min_single(const rk_db *db) { return db->info.bits_per_symbol == 5 ? RK_HASH_MIN_BRANCHES_AA : RK_HASH_MIN_BRANCHES; }
+}
+static uint32_t hash_min_single(double est_units) {
+    const uint32_t u = hash_min_uniform(est_units) + 8000u;
+    return u > RK_HASH_MIN_BRANCHES_CLADE ? RK_HASH_MIN_BRANCHES_CLADE : u;
+}
 static bool hash_capable(const rk_db *db) {  // images whose tiles can go to place_hash64_kernel first
     if (rk_knob("RK_NO_HASH") || rk_knob("RK_NO_WSTREAM") || db->info.rows_bytes >= ROWS_FIT32_LIMIT) return false;
     return rk_knob("RK_HASH_ALWAYS") || db->wp.stream;
 }
-static bool hash_tree(const rk_db *db) {  // ... by the single rule
+static bool hash_tree(const rk_db *db, double est_units) {  // ... by the single rule
     if (!hash_capable(db)) return false;
-    return rk_knob("RK_HASH_ALWAYS") || db->info.n_branches > hash_min_single(db);
+    return rk_knob("RK_HASH_ALWAYS") || db->info.n_branches > hash_min_single(est_units);
 }
 static uint32_t hash_key_limit() {
     uint32_t slack = RK_HASH_KEY_SLACK;
@@ -1522,8 +1525,8 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     // pre-pass (a.perm: its verdict on the batch's shape is on the device), both are launched and one of them returns at once
     const uint32_t nb_tree = db->info.n_branches;
     const bool forced = rk_knob("RK_HASH_ALWAYS") != nullptr;
-    const bool by_shape = hash_fits && sorted_fits && !forced && a.perm != nullptr && nb_tree > hash_min_uniform(db) && nb_tree <= RK_HASH_MIN_BRANCHES_CLADE;
-    const bool hash_first = hash_fits && (forced || by_shape || nb_tree > (a.perm != nullptr ? RK_HASH_MIN_BRANCHES_CLADE : hash_min_single(db)) || (!sorted_fits && hash_tree(db)));
+    const bool by_shape = hash_fits && sorted_fits && !forced && a.perm != nullptr && nb_tree > hash_min_uniform(est_units) && nb_tree <= RK_HASH_MIN_BRANCHES_CLADE;
+    const bool hash_first = hash_fits && (forced || by_shape || nb_tree > (a.perm != nullptr ? RK_HASH_MIN_BRANCHES_CLADE : hash_min_single(est_units)) || (!sorted_fits && hash_tree(db, est_units)));
     const bool sorted_first = sorted_fits && (by_shape || !hash_first);
     if (hash_first && first_ok) {
         PlaceArgs b = a;
@@ -1808,12 +1811,13 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
+        const double est_name = (db->info.bits_per_symbol == 5 ? 100.0 - db->info.k + 1 : 150.0 - db->info.k + 1) * db->wp.units_per_code;  // (the reads of BASELINE's configs)
         const bool hash_fits = hash_capable(db) && (rk_knob("RK_HASH_ALWAYS") || 141.0 * db->wp.units_per_code * 9.3 <= 0.8 * hash_key_limit());
-        const bool band = hash_fits && !rk_knob("RK_HASH_ALWAYS") && db->wp.stream && db->info.n_branches > hash_min_uniform(db) && db->info.n_branches <= RK_HASH_MIN_BRANCHES_CLADE;
-        if (hash_fits && (band || hash_tree(db)))
+        const bool band = hash_fits && !rk_knob("RK_HASH_ALWAYS") && db->wp.stream && db->info.n_branches > hash_min_uniform(est_name) && db->info.n_branches <= RK_HASH_MIN_BRANCHES_CLADE;
+        if (hash_fits && (band || hash_tree(db, est_name)))
             snprintf(buf, sizeof(buf), "place_hash64_kernel<BITS=%u,U=%d,NPL=%d,PU=%d,LOGS=%u> %u slots, <= %u keys a read%s (+ place_packed16w_kernel for the tiles it hands over; windows=%u x %u branches)",
                      db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, RK_HASH_LOG_SLOTS, 1u << RK_HASH_LOG_SLOTS, hash_key_limit(),
-                     band ? (db->info.n_branches > hash_min_single(db) ? " | place_packed16s_kernel for batches of clade-shaped reads" : " for batches of uniform reads of 32 768 or more | place_packed16s_kernel otherwise") : "",
+                     band ? (db->info.n_branches > hash_min_single(est_name) ? " | place_packed16s_kernel for batches of clade-shaped reads" : " for batches of uniform reads of 32 768 or more | place_packed16s_kernel otherwise") : "",
                      db->wp.n_win, db->wp.W);
         else if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
             snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
