@@ -23,6 +23,7 @@ CONFIGS = {
     "T4k": (4, 10, 2_000, 786_432, 10_000_000, 150, 4_000_000),
     "T8k": (4, 10, 4_000, 786_432, 10_000_000, 150, 4_000_000),
     "T20k": (4, 10, 10_000, 786_432, 10_000_000, 150, 2_000_000),
+    "T40k": (4, 10, 20_000, 786_432, 10_000_000, 150, 2_000_000),  # (39 999 branches: between the two crossings of the short-row kernels)
     "T64k": (4, 10, 32_768, 786_432, 10_000_000, 150, 2_000_000),
     # not BASELINE configs either: long rows on trees between the dense kernels' and the workgroup-per-read kernel's regimes (a quarter
     # of the 9-mers present; rows of 400 entries on 9 001 branches, of 1 000 on 15 999: scripts/long_rows_big_tree.py as bench lines)
