@@ -1473,31 +1473,49 @@ constexpr uint32_t RK_HASH_LOG_SLOTS = RK_HASH_LOGS, RK_HASH_MAIN_CAP = 320;
 // crossings -- 145 units a read (C2, 150 bp) at 28 000 branches, 33 (C4-like, 100 residues) at 13 500 -- the uniform crossing is taken as
 // 130 branches per unit + 9 250 for other row densities and read lengths; batches too small for the pre-pass go by that + 8 000
 // (36 000 for C2-like rows).  -DRK_HASH_MIN_BRANCHES_UNIFORM_FIXED=n replaces the fit by a constant.
-static uint32_t hash_min_uniform(double est_units) {
+// Reads that bring few row entries even when every k-mer of theirs has a row take the table of 1 024 slots (hash_small_table): sixteen waves
+// per CU, half the reset and the scan.  Forced onto the protein sweep above (RK_HASH_SMALL_TABLE; its reads hit a quarter of their k-mers, a real
+// read would overflow that table) it gives 310 Mreads/s on uniform reads and 170 on clade-shaped ones at every size, and the crossings move to ~2 600 branches
+// (place_packed16s_kernel: 329 / 297 at 2 001 / 3 100) and ~24 000 (181 / 168 / 151 at 15 999 / 25 001 / 33 001).  One measured crossing only in
+// this regime: 19 branches per unit + 2 000 (a tree of four windows: the table's reset and scan do not shrink with the read) passes through it.
+static uint32_t hash_min_clade(bool small_table) { return small_table ? 24000u : RK_HASH_MIN_BRANCHES_CLADE; }
+static uint32_t hash_min_uniform(double est_units, bool small_table) {
 #ifdef RK_HASH_MIN_BRANCHES_UNIFORM_FIXED
     (void)est_units;
     return RK_HASH_MIN_BRANCHES_UNIFORM_FIXED;
 #else
-    const double nb = 130.0 * est_units + 9250.0;
-    return nb > (double)RK_HASH_MIN_BRANCHES_CLADE ? RK_HASH_MIN_BRANCHES_CLADE : (uint32_t)nb;
+    const double nb = small_table ? 19.0 * est_units + 2000.0 : 130.0 * est_units + 9250.0;
+    return nb > (double)hash_min_clade(small_table) ? hash_min_clade(small_table) : (uint32_t)nb;
 #endif
 }
-static uint32_t hash_min_single(double est_units) {
-    const uint32_t u = hash_min_uniform(est_units) + 8000u;
-    return u > RK_HASH_MIN_BRANCHES_CLADE ? RK_HASH_MIN_BRANCHES_CLADE : u;
+static uint32_t hash_min_single(double est_units, bool small_table) {
+    const uint32_t u = hash_min_uniform(est_units, small_table) + 8000u;
+    return u > hash_min_clade(small_table) ? hash_min_clade(small_table) : u;
 }
 static bool hash_capable(const rk_db *db) {  // images whose tiles can go to place_hash64_kernel first
     if (rk_knob("RK_NO_HASH") || rk_knob("RK_NO_WSTREAM") || db->info.rows_bytes >= ROWS_FIT32_LIMIT) return false;
     return rk_knob("RK_HASH_ALWAYS") || db->wp.stream;
 }
-static bool hash_tree(const rk_db *db, double est_units) {  // ... by the single rule
+static bool hash_tree(const rk_db *db, double est_units, bool small_table) {  // ... by the single rule
     if (!hash_capable(db)) return false;
-    return rk_knob("RK_HASH_ALWAYS") || db->info.n_branches > hash_min_single(est_units);
+    return rk_knob("RK_HASH_ALWAYS") || db->info.n_branches > hash_min_single(est_units, small_table);
 }
-static uint32_t hash_key_limit() {
+static uint32_t hash_key_limit(uint32_t log_slots);
+// The table of 1 024 slots: est_units < 0 asks "in no case"; otherwise est_units holds the row ENTRIES of a read all of whose k-mers have a
+// row (mean row length x its k-mers) -- what a read from an organism of the reference brings, four times the uniform estimate of C4-like
+// rows -- and the small table is taken only when even that fits: a read that overflows costs a tile of place_packed16w_kernel.
+static bool hash_small_table(double full_hit_entries) {
+    if (rk_knob("RK_HASH_BIG_TABLE") || full_hit_entries < 0.0) return false;  // (developer knob: A/B)
+    return rk_knob("RK_HASH_SMALL_TABLE") != nullptr || full_hit_entries <= 0.8 * hash_key_limit(RK_HASH_LOG_SLOTS - 1);
+}
+static double full_hit_entries(const rk_db *db, uint32_t symbols) {
+    const double kmers = symbols > db->info.k ? (double)(symbols - db->info.k + 1) : 0.0;
+    return db->info.n_keys ? kmers * (double)db->info.n_entries / (double)db->info.n_keys : 0.0;
+}
+static uint32_t hash_key_limit(uint32_t log_slots = RK_HASH_LOG_SLOTS) {
     uint32_t slack = RK_HASH_KEY_SLACK;
     if (const char *e = rk_knob("RK_HASH_KEY_SLACK")) slack = (uint32_t)atoi(e);  // developer knob
-    const uint32_t ns = 1u << RK_HASH_LOG_SLOTS;
+    const uint32_t ns = 1u << log_slots;
     if (slack < 16u) slack = 16u;
     if (slack > ns - 64u) slack = ns - 64u;
     return ns - slack;
@@ -1517,6 +1535,9 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     // place_hash64_kernel first: images of short rows (the rule place_packed16s_kernel had), reads whose distinct branches -- at most
     // their entries, ~9.3 a unit with C2-like rows -- fit the table (profiles/r04_lsize_hist.txt)
     const bool hash_fits = !no_stream && hash_capable(db) && (est_units * 9.3 <= 0.8 * hash_key_limit() || rk_knob("RK_HASH_ALWAYS"));
+    // reads of few row units (a protein database: ~300 entries a read): a table of 1 024 slots -- half the reset and the scan, 9.7 KB a
+    // wave, sixteen waves per CU instead of nine
+    const bool hash_small = hash_small_table(full_hit_entries(db, max_syms));
     const bool sorted_fits = a.words_per_read <= 16 && !no_stream && wp.stream && one_batch && (est_units <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
     TileOrder order;
     if (int rc = order.prepare(db, a, stream, hash_fits || sorted_fits)) return rc;
@@ -1525,13 +1546,14 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     // pre-pass (a.perm: its verdict on the batch's shape is on the device), both are launched and one of them returns at once
     const uint32_t nb_tree = db->info.n_branches;
     const bool forced = rk_knob("RK_HASH_ALWAYS") != nullptr;
-    const bool by_shape = hash_fits && sorted_fits && !forced && a.perm != nullptr && nb_tree > hash_min_uniform(est_units) && nb_tree <= RK_HASH_MIN_BRANCHES_CLADE;
-    const bool hash_first = hash_fits && (forced || by_shape || nb_tree > (a.perm != nullptr ? RK_HASH_MIN_BRANCHES_CLADE : hash_min_single(est_units)) || (!sorted_fits && hash_tree(db, est_units)));
+    const bool by_shape = hash_fits && sorted_fits && !forced && a.perm != nullptr && nb_tree > hash_min_uniform(est_units, hash_small) && nb_tree <= hash_min_clade(hash_small);
+    const bool hash_first = hash_fits && (forced || by_shape || nb_tree > (a.perm != nullptr ? hash_min_clade(hash_small) : hash_min_single(est_units, hash_small)) || (!sorted_fits && hash_tree(db, est_units, hash_small)));
     const bool sorted_first = sorted_fits && (by_shape || !hash_first);
     if (hash_first && first_ok) {
         PlaceArgs b = a;
         b.only_if = by_shape ? 1u : 0u;  // (uniform reads: the batch kept its order)
-        b.s_stride = 1u << RK_HASH_LOG_SLOTS; b.main_cap = RK_HASH_MAIN_CAP; b.work_cap = hash_key_limit(); b.list_cap = 0; b.only_marked = 0;
+        const uint32_t log_slots = hash_small ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS;
+        b.s_stride = 1u << log_slots; b.main_cap = RK_HASH_MAIN_CAP; b.work_cap = hash_key_limit(log_slots); b.list_cap = 0; b.only_marked = 0;
         const size_t lds_wave = (size_t)(2 * b.s_stride + 64 + b.main_cap) * 4;
         auto launch = [&](auto kern) -> int {
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
@@ -1544,7 +1566,9 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds_wave, stream, b);
             return RK_OK;
         };
-        int rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS>);
+        int rc;
+        if (hash_small) rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS - 1>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS - 1>);
+        else rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS>);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
     }
@@ -1813,11 +1837,13 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     if (use_windowed(db, 7, 16)) {
         const double est_name = (db->info.bits_per_symbol == 5 ? 100.0 - db->info.k + 1 : 150.0 - db->info.k + 1) * db->wp.units_per_code;  // (the reads of BASELINE's configs)
         const bool hash_fits = hash_capable(db) && (rk_knob("RK_HASH_ALWAYS") || 141.0 * db->wp.units_per_code * 9.3 <= 0.8 * hash_key_limit());
-        const bool band = hash_fits && !rk_knob("RK_HASH_ALWAYS") && db->wp.stream && db->info.n_branches > hash_min_uniform(est_name) && db->info.n_branches <= RK_HASH_MIN_BRANCHES_CLADE;
-        if (hash_fits && (band || hash_tree(db, est_name)))
+        const bool small_name = hash_small_table(full_hit_entries(db, db->info.bits_per_symbol == 5 ? 100u : 150u));
+        const bool band = hash_fits && !rk_knob("RK_HASH_ALWAYS") && db->wp.stream && db->info.n_branches > hash_min_uniform(est_name, small_name) && db->info.n_branches <= hash_min_clade(small_name);
+        if (hash_fits && (band || hash_tree(db, est_name, small_name)))
             snprintf(buf, sizeof(buf), "place_hash64_kernel<BITS=%u,U=%d,NPL=%d,PU=%d,LOGS=%u> %u slots, <= %u keys a read%s (+ place_packed16w_kernel for the tiles it hands over; windows=%u x %u branches)",
-                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, RK_HASH_LOG_SLOTS, 1u << RK_HASH_LOG_SLOTS, hash_key_limit(),
-                     band ? (db->info.n_branches > hash_min_single(est_name) ? " | place_packed16s_kernel for batches of clade-shaped reads" : " for batches of uniform reads of 32 768 or more | place_packed16s_kernel otherwise") : "",
+                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, small_name ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS,
+                     1u << (small_name ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS), hash_key_limit(small_name ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS),
+                     band ? (db->info.n_branches > hash_min_single(est_name, small_name) ? " | place_packed16s_kernel for batches of clade-shaped reads" : " for batches of uniform reads of 32 768 or more | place_packed16s_kernel otherwise") : "",
                      db->wp.n_win, db->wp.W);
         else if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
             snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",

@@ -855,7 +855,7 @@ def test_protein_records_filled_to_the_last_word(n_branches):
     sdb = synth.make_db(20, 5, n_branches, 30000, 300000, seed=n_branches)
     odb = O.OracleDB.from_synth(sdb)
     db = ra.PhyloKmerDB.from_synth(sdb)
-    assert "PU=7" in db.kernel_name(), db.kernel_name()
+    assert "PU=7" in db.kernel_name() or "place_hash64_kernel<BITS=5" in db.kernel_name(), db.kernel_name()  # (the hash kernel probes 2 x 64 k-mers; it takes batches of 32 768 reads or more)
     db.close()
     rng = np.random.default_rng(n_branches)
     lens = rng.integers(95, 103, 1200)
@@ -918,19 +918,29 @@ def test_hash_kernel_units_of_a_step_that_meet_in_a_branch(n_branches, monkeypat
         assert st["placed"] > 1900
 
 
-@pytest.mark.parametrize("n_branches", [30001, 52001])
-def test_first_kernel_by_the_shape_of_the_batch(n_branches, monkeypatch, dev_lib):
-    """between the two crossing points (28 000 / 56 000 branches) place_hash64_kernel and place_packed16s_kernel are both launched and the
-    verdict of the re-tiling pre-pass on the batch -- uniform reads keep their order, reads of a clade are re-tiled -- says which of
-    them runs: a clade-shaped batch, a uniform one and a mixed one all equal the oracle (the pre-pass switched on for small batches)"""
+@pytest.mark.parametrize("rows,n_branches", [("sparse", 12001), ("sparse", 20001), ("dense", 40001), ("sparse-small-table", 12001), ("sparse-small-table", 30001)])
+def test_first_kernel_by_the_shape_of_the_batch(rows, n_branches, monkeypatch, dev_lib):
+    """between the two crossing points of a database (C2-like rows: 28 000 / 56 000 branches; few row units a read, the 1 024-slot table:
+    ~2 000 / 24 000) place_hash64_kernel and place_packed16s_kernel are both launched and the verdict of the re-tiling pre-pass on the
+    batch -- uniform reads keep their order, reads of a clade are re-tiled -- says which of them runs: a clade-shaped batch, a uniform one
+    and a mixed one all equal the oracle (the pre-pass switched on for small batches)"""
     monkeypatch.setenv("RK_RETILE_MIN_READS", "0")
-    sdb, genome = _clade_db(9, n_branches, 6000, seed=n_branches, mean_row=12.0)
+    if rows.endswith("small-table"):  # (the 1 024-slot instantiation: taken by itself only when a read all of whose k-mers hit fits it)
+        monkeypatch.setenv("RK_HASH_SMALL_TABLE", "1")
+    if rows.startswith("sparse"):
+        sdb, genome = _clade_db(9, n_branches, 6000, seed=n_branches, mean_row=12.0)
+        s1, o1 = synth.make_motif_reads(genome, 2500, 150, seed=5, amb_rate=0.001, var_len=40)
+    else:
+        sdb, g = synth.make_clade_db(k=10, n_branches=n_branches, genome_len=400_000)
+        s1, o1 = synth.make_clade_reads(g, 2500, 150)
     odb = O.OracleDB.from_synth(sdb)
     db = ra.PhyloKmerDB.from_synth(sdb)
     name = db.kernel_name()
     db.close()
-    assert "place_hash64_kernel" in name and "place_packed16s_kernel" in name, name
-    s1, o1 = synth.make_motif_reads(genome, 2500, 150, seed=5, amb_rate=0.001, var_len=40)
+    if n_branches == 30001:  # (beyond the small table's clade crossing: the hash kernel alone)
+        assert "place_hash64_kernel" in name and "place_packed16s_kernel" not in name and "LOGS=10" in name, name
+    else:
+        assert "place_hash64_kernel" in name and "place_packed16s_kernel" in name and ("LOGS=10" if rows.endswith("small-table") else "LOGS=11") in name, name
     s2, o2 = synth.make_reads(4, 2500, 150, seed=6, var_len=60, amb_rate=0.001, bad_rate=0.002)
     for seq, off in ((s1, o1), (s2, o2), (np.concatenate([s1, s2]), np.concatenate([o1, o2[1:] + o1[-1]]))):
         for K in (7, 12):
