@@ -1478,6 +1478,18 @@ constexpr uint32_t RK_HASH_LOG_SLOTS = RK_HASH_LOGS, RK_HASH_MAIN_CAP = 320;
 // read would overflow that table) it gives 310 Mreads/s on uniform reads and 170 on clade-shaped ones at every size, and the crossings move to ~2 600 branches
 // (place_packed16s_kernel: 329 / 297 at 2 001 / 3 100) and ~24 000 (181 / 168 / 151 at 15 999 / 25 001 / 33 001).  One measured crossing only in
 // this regime: 19 branches per unit + 2 000 (a tree of four windows: the table's reset and scan do not shrink with the read) passes through it.
+// (clade-shaped batches through the 1 024-slot table with the large one behind it: DNA 96 - 100 Mreads/s at any size against place_packed16s_kernel's
+//  128 / 106 / 95 / 92 / 84 / 48 at 19 999 / 33 001 / 46 001 / 50 001 / 55 001 / 60 001 branches -- they cross at ~42 000; amino acids 170 against
+//  181 / 168 / 151 at 15 999 / 25 001 / 33 001: ~24 000.  Through both: 160 branches per row unit of a read + 18 700)
+static uint32_t hash_min_clade_small(double est_units) {
+#ifdef RK_HASH_MIN_BRANCHES_CLADE_SMALL
+    (void)est_units;
+    return RK_HASH_MIN_BRANCHES_CLADE_SMALL;
+#else
+    const double nb = 160.0 * est_units + 18700.0;
+    return nb > 65535.0 ? 65535u : (uint32_t)nb;
+#endif
+}
 static uint32_t hash_min_clade(bool small_table) { return small_table ? 24000u : RK_HASH_MIN_BRANCHES_CLADE; }
 static uint32_t hash_min_uniform(double est_units, bool small_table) {
 #ifdef RK_HASH_MIN_BRANCHES_UNIFORM_FIXED
@@ -1542,18 +1554,34 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     TileOrder order;
     if (int rc = order.prepare(db, a, stream, hash_fits || sorted_fits)) return rc;
     const bool first_ok = a.tile_marks != nullptr;  // (no scratch to be had for the marks: place_packed16w_kernel alone)
-    // which of the two goes first: by the tree's size; between the two crossing points, and when the batch went through the re-tiling
-    // pre-pass (a.perm: its verdict on the batch's shape is on the device), both are launched and one of them returns at once
+    // Which kernel goes first, for a batch of uniform reads and for a batch of reads of a clade.  When the batch went through the re-tiling
+    // pre-pass (a.perm) its verdict on the batch's shape is on the device: if the two choices differ both kernels are launched and one of
+    // them returns at once (PlaceArgs::only_if).  Without the verdict (small batches) one rule serves both.
+    enum First { F_NONE, F_SORTED, F_HASH_BIG, F_HASH_SMALL };
     const uint32_t nb_tree = db->info.n_branches;
     const bool forced = rk_knob("RK_HASH_ALWAYS") != nullptr;
-    const bool by_shape = hash_fits && sorted_fits && !forced && a.perm != nullptr && nb_tree > hash_min_uniform(est_units, hash_small) && nb_tree <= hash_min_clade(hash_small);
-    const bool hash_first = hash_fits && (forced || by_shape || nb_tree > (a.perm != nullptr ? hash_min_clade(hash_small) : hash_min_single(est_units, hash_small)) || (!sorted_fits && hash_tree(db, est_units, hash_small)));
-    const bool sorted_first = sorted_fits && (by_shape || !hash_first);
-    if (hash_first && first_ok) {
+    const bool verdict = a.perm != nullptr;
+    const First table_u = hash_small ? F_HASH_SMALL : F_HASH_BIG;
+    First for_uniform, for_clade;
+    if (forced && hash_fits) {
+        for_uniform = for_clade = table_u;
+    } else {
+        const uint32_t min_u = verdict ? hash_min_uniform(est_units, hash_small) : hash_min_single(est_units, hash_small);
+        for_uniform = hash_fits && nb_tree > min_u ? table_u : sorted_fits ? F_SORTED : hash_fits && hash_tree(db, est_units, hash_small) ? table_u : F_NONE;
+        for_clade = for_uniform;
+        if (verdict) {
+            // reads of a clade touch a third of the branches uniform reads do (profiles/r04_lsize_hist.txt: ~500 against ~1 300; max 1 135): their
+            // tables fit the 1 024-slot instantiation -- sixteen waves per CU -- and the few that do not are placed by the large one, launched
+            // behind it on the tiles it hands over
+            const bool clade_small = hash_fits && !hash_small && (rk_knob("RK_HASH_CLADE_SMALL") || nb_tree > hash_min_clade_small(est_units)) && !rk_knob("RK_HASH_BIG_TABLE");
+            for_clade = clade_small ? F_HASH_SMALL : hash_fits && nb_tree > hash_min_clade(hash_small) ? table_u : sorted_fits ? F_SORTED : for_uniform;
+        }
+    }
+    const bool two = for_uniform != for_clade;
+    auto launch_hash = [&](uint32_t log_slots, uint32_t only_if, uint32_t only_marked) -> int {
         PlaceArgs b = a;
-        b.only_if = by_shape ? 1u : 0u;  // (uniform reads: the batch kept its order)
-        const uint32_t log_slots = hash_small ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS;
-        b.s_stride = 1u << log_slots; b.main_cap = RK_HASH_MAIN_CAP; b.work_cap = hash_key_limit(log_slots); b.list_cap = 0; b.only_marked = 0;
+        b.only_if = only_if;
+        b.s_stride = 1u << log_slots; b.main_cap = RK_HASH_MAIN_CAP; b.work_cap = hash_key_limit(log_slots); b.list_cap = 0; b.only_marked = only_marked;
         const size_t lds_wave = (size_t)(2 * b.s_stride + 64 + b.main_cap) * 4;
         auto launch = [&](auto kern) -> int {
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
@@ -1567,17 +1595,46 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
             return RK_OK;
         };
         int rc;
-        if (hash_small) rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS - 1>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS - 1>);
+        if (log_slots != RK_HASH_LOG_SLOTS) rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS - 1>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS - 1>);
         else rc = db->info.bits_per_symbol == 2 ? launch(place_hash64_kernel<2, RK_HRING, RK_HNPL, 3, RK_HASH_LOG_SLOTS>) : launch(place_hash64_kernel<5, RK_HRING, RK_HNPL, 2, RK_HASH_LOG_SLOTS>);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
+        return RK_OK;
+    };
+    auto compact_marks = [&]() -> int {  // the marked tiles as a list + the queue's counters, for the next launch
+        if (!a.marked_list) return RK_OK;
+        HIP_TRY(hipMemsetAsync(a.marked_ctl, 0, 8, stream));
+        const unsigned nblk = (unsigned)std::min<uint64_t>((n_tiles + 255) / 256, 1024);
+        hipLaunchKernelGGL(compact_marks_kernel, dim3(nblk), dim3(256), 0, stream, (const unsigned char *)a.tile_marks, n_tiles, a.marked_list, a.marked_ctl);
+        HIP_TRY(hipGetLastError());
+        return RK_OK;
+    };
+    bool any_first = false, small_on_trust = false;
+    if (first_ok) {
+        for (int which = 0; which < 2; which++) {  // 0: the kernel of uniform batches, 1: that of clade-shaped ones (when it is another)
+            if (which == 1 && !two) break;
+            const First f = which == 0 ? for_uniform : for_clade;
+            const uint32_t only_if = two ? (which == 0 ? 1u : 2u) : 0u;
+            if (f == F_HASH_BIG || f == F_HASH_SMALL) {
+                if (int rc = launch_hash(f == F_HASH_SMALL ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS, only_if, 0u)) return rc;
+                any_first = true;
+                small_on_trust = small_on_trust || (f == F_HASH_SMALL && !hash_small);
+            }
+        }
+        if (small_on_trust && a.marked_list) {  // the tiles the small table handed over: the large one next, then place_packed16w_kernel for what is left
+            if (int rc = compact_marks()) return rc;
+            if (int rc = launch_hash(RK_HASH_LOG_SLOTS, 0u, 1u)) return rc;
+        }
     }
-    if (sorted_first && first_ok) {
+    const bool sorted_first = first_ok && (for_uniform == F_SORTED || for_clade == F_SORTED);
+    const uint32_t sorted_only_if = two ? (for_uniform == F_SORTED ? 1u : 2u) : 0u;
+    const bool hash_first = any_first;
+    if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on
         //      the largest windows, eight otherwise; the list holds a C2-like read (145 units, 250 at the tail) with the padding of
         //      its window segments ----
         PlaceArgs b = a;
-        b.only_if = by_shape ? 2u : 0u;  // (reads of a clade: the batch was re-tiled)
+        b.only_if = sorted_only_if;  // (when another kernel takes batches of the other shape)
         const uint32_t work_min = 96u;  // scratch of the second pass: 48 candidate keys
         // ring of row loads: eight deep, a window's segment padded to half turns of it (four deep it left the stream waiting
         // on HBM: ~280 cycles a step; segments padded to whole turns of eight made the largest trees' lists half filler)
@@ -1622,11 +1679,8 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     }
     // ---- place_packed16w_kernel: every tile (records of more than 16 words), or the tiles the first kernel handed over ----
     a.only_marked = ((hash_first || sorted_first) && first_ok) ? 1u : 0u;
-    if (a.only_marked && a.marked_list) {
-        const unsigned nblk = (unsigned)std::min<uint64_t>((n_tiles + 255) / 256, 1024);
-        hipLaunchKernelGGL(compact_marks_kernel, dim3(nblk), dim3(256), 0, stream, (const unsigned char *)a.tile_marks, n_tiles, a.marked_list, a.marked_ctl);
-        HIP_TRY(hipGetLastError());
-    }
+    if (a.only_marked)
+        if (int rc = compact_marks()) return rc;
     // 88 words = the 44 keys the exact select of a window needs as scratch for keep_at_most <= 8 (K + 16 candidates + 16 winners); 96 beyond
     const uint32_t work_min = a.keep_at_most > 8 ? 96u : 88u;
     if (wp.work_cap < work_min) {

@@ -2612,7 +2612,19 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
     };
 
     const u64 n_tiles = (a.n_reads + 3) / 4;
-    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // As a second launch (only_marked: behind the instantiation with the small table) the waves take the tiles that one handed over from the
+    // queue place_packed16w_kernel uses, clear a tile's mark and set it again if they cannot place it either
+    const bool queued = a.only_marked != 0u && a.marked_list != nullptr;
+    auto take_marked = [&]() -> u64 {
+        u32 i = 0;
+        if (lane == 0) i = atomicAdd(&a.marked_ctl[1], 1u);
+        i = (u32)__builtin_amdgcn_readfirstlane((int)i);
+        const u32 n_marked = (u32)__builtin_amdgcn_readfirstlane((int)a.marked_ctl[0]);
+        return i < n_marked ? (u64)(u32)__builtin_amdgcn_readfirstlane((int)a.marked_list[i]) : n_tiles;
+    };
+    if (a.only_marked != 0u && !queued) return;  // (never launched that way)
+    for (u64 tile = queued ? take_marked() : (u64)blockIdx.x; tile < n_tiles; tile = queued ? take_marked() : tile + gridDim.x) {
+        if (queued && lane == 0) a.tile_marks[tile] = 0;
         bool handed = false;  // (wave-uniform) some read of the tile is left to place_packed16w_kernel
         for (u32 g = 0; g < 4u; g++) {
             const u64 slot = tile * 4 + g;

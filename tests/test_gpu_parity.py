@@ -918,7 +918,7 @@ def test_hash_kernel_units_of_a_step_that_meet_in_a_branch(n_branches, monkeypat
         assert st["placed"] > 1900
 
 
-@pytest.mark.parametrize("rows,n_branches", [("sparse", 12001), ("sparse", 20001), ("dense", 40001), ("sparse-small-table", 12001), ("sparse-small-table", 30001)])
+@pytest.mark.parametrize("rows,n_branches", [("sparse", 12001), ("sparse", 20001), ("dense", 40001), ("dense", 60001), ("sparse-small-table", 12001), ("sparse-small-table", 30001)])
 def test_first_kernel_by_the_shape_of_the_batch(rows, n_branches, monkeypatch, dev_lib):
     """between the two crossing points of a database (C2-like rows: 28 000 / 56 000 branches; few row units a read, the 1 024-slot table:
     ~2 000 / 24 000) place_hash64_kernel and place_packed16s_kernel are both launched and the verdict of the re-tiling pre-pass on the
@@ -937,7 +937,9 @@ def test_first_kernel_by_the_shape_of_the_batch(rows, n_branches, monkeypatch, d
     db = ra.PhyloKmerDB.from_synth(sdb)
     name = db.kernel_name()
     db.close()
-    if n_branches == 30001:  # (beyond the small table's clade crossing: the hash kernel alone)
+    if n_branches == 60001:  # (uniform batches: the large table; clade-shaped ones: the small table with the large one behind it for the tiles it hands over)
+        assert "place_hash64_kernel" in name and "place_packed16s_kernel" not in name, name
+    elif n_branches == 30001:  # (beyond the small table's clade crossing: the hash kernel alone)
         assert "place_hash64_kernel" in name and "place_packed16s_kernel" not in name and "LOGS=10" in name, name
     else:
         assert "place_hash64_kernel" in name and "place_packed16s_kernel" in name and ("LOGS=10" if rows.endswith("small-table") else "LOGS=11") in name, name
