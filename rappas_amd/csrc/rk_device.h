@@ -83,8 +83,9 @@ struct PlaceArgs {
     u32 n_pass;    // large-tree kernels: branch-range passes per read (1 unless the score vector exceeds one CU's LDS)
     u32 main_cap, work_cap;  // windowed kernels: u32 slots of the per-read item list / of the per-window work (touched-slot) list
     u32 only_marked;         // place_packed16w_kernel as the second launch: only the tiles marked in tile_marks
-    u32 only_if;             // place_hash64_kernel / place_packed16s_kernel launched side by side: 0 = run; 1 = only for a batch that keeps its order
-                             // (uniform reads: *keep_order != 0), 2 = only for a re-tiled batch (reads of a clade); needs perm / keep_order
+    u32 only_if;             // first kernels launched side by side: 0 = run; else the classes of batches this launch is for, as the pre-pass judged the
+                             // batch on the device -- bit 0: uniform reads (*keep_order != 0) whose sampled k-mers have a row more often than a random
+                             // read's, bit 1: uniform reads that hit no more often than that (keep_order[3] != 0), bit 2: reads of a clade (re-tiled)
     unsigned char *tile_marks;  // [ceil(n_reads / 4)] scratch of the launch (zeroed before the first kernel): tile t -- the reads at slots 4t .. 4t+3 of the
                                 // batch's order -- is left to place_packed16w_kernel by the kernel launched ahead of it (never the caller's flag array:
                                 // d_flags_in may be the same buffer as the output flags)

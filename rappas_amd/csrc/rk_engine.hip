@@ -1436,7 +1436,12 @@ struct TileOrder {
         const unsigned sblk = (unsigned)((a.n_reads / 64 + 255) / 256 + 1);
         if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_sample_kernel<2>, dim3(sblk), dim3(256), 0, s, a, hist);
         else hipLaunchKernelGGL(retile_sample_kernel<5>, dim3(sblk), dim3(256), 0, s, a, hist);
-        hipLaunchKernelGGL(retile_decide_kernel, dim3(1), dim3(64), 0, s, hist);
+        // (a batch is "sparse" when its sampled k-mers have a row at most 1.3 times as often as a random read's: the share of the alphabet's
+        //  k-mer codes that carry one)
+        double space = 1.0;
+        for (uint32_t i = 0; i < db->info.k; i++) space *= (double)db->info.alphabet;
+        const double share = std::min(1.0, 1.3 * (double)db->info.n_keys / space);
+        hipLaunchKernelGGL(retile_decide_kernel, dim3(1), dim3(64), 0, s, hist, (uint32_t)(share * 65536.0));
         if (db->info.bits_per_symbol == 2) hipLaunchKernelGGL(retile_key_kernel<2>, dim3(nblk), dim3(256), 0, s, a, keys, hist);
         else hipLaunchKernelGGL(retile_key_kernel<5>, dim3(nblk), dim3(256), 0, s, a, keys, hist);
         hipLaunchKernelGGL(retile_scan_kernel, dim3(1), dim3(64), 0, s, hist, cursor);
@@ -1577,7 +1582,20 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
             for_clade = clade_small ? F_HASH_SMALL : hash_fits && nb_tree > hash_min_clade(hash_small) ? table_u : sorted_fits ? F_SORTED : for_uniform;
         }
     }
-    const bool two = for_uniform != for_clade;
+    // uniform batches whose k-mers hit no more often than a random read's (the pre-pass's second verdict): the uniform estimate of a read's
+    // entries holds, and where that fits the 1 024-slot table the small instantiation serves them (the large one behind it, as for clades)
+    First for_sparse = for_uniform;
+    if (verdict && !forced && hash_fits && !hash_small && !rk_knob("RK_HASH_BIG_TABLE") && est_units * 9.3 <= 0.6 * hash_key_limit(RK_HASH_LOG_SLOTS - 1) &&
+        nb_tree > hash_min_uniform(est_units, true))
+        for_sparse = F_HASH_SMALL;
+    // every distinct kernel once, with the classes of batches it serves (PlaceArgs::only_if: bit 0 uniform reads that hit often, bit 1
+    // uniform reads that hit like random ones, bit 2 reads of a clade; all three = unconditional)
+    const First by_class[3] = {for_uniform, for_sparse, for_clade};
+    auto class_mask = [&](First f) -> uint32_t {
+        uint32_t m = 0;
+        for (int c = 0; c < 3; c++) m |= by_class[c] == f ? 1u << c : 0u;
+        return m;
+    };
     auto launch_hash = [&](uint32_t log_slots, uint32_t only_if, uint32_t only_marked) -> int {
         PlaceArgs b = a;
         b.only_if = only_if;
@@ -1611,23 +1629,20 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     };
     bool any_first = false, small_on_trust = false;
     if (first_ok) {
-        for (int which = 0; which < 2; which++) {  // 0: the kernel of uniform batches, 1: that of clade-shaped ones (when it is another)
-            if (which == 1 && !two) break;
-            const First f = which == 0 ? for_uniform : for_clade;
-            const uint32_t only_if = two ? (which == 0 ? 1u : 2u) : 0u;
-            if (f == F_HASH_BIG || f == F_HASH_SMALL) {
-                if (int rc = launch_hash(f == F_HASH_SMALL ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS, only_if, 0u)) return rc;
-                any_first = true;
-                small_on_trust = small_on_trust || (f == F_HASH_SMALL && !hash_small);
-            }
+        for (First f : {F_HASH_SMALL, F_HASH_BIG}) {
+            const uint32_t m = class_mask(f);
+            if (!m) continue;
+            if (int rc = launch_hash(f == F_HASH_SMALL ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS, m == 7u ? 0u : m, 0u)) return rc;
+            any_first = true;
+            small_on_trust = small_on_trust || (f == F_HASH_SMALL && !hash_small);
         }
         if (small_on_trust && a.marked_list) {  // the tiles the small table handed over: the large one next, then place_packed16w_kernel for what is left
             if (int rc = compact_marks()) return rc;
             if (int rc = launch_hash(RK_HASH_LOG_SLOTS, 0u, 1u)) return rc;
         }
     }
-    const bool sorted_first = first_ok && (for_uniform == F_SORTED || for_clade == F_SORTED);
-    const uint32_t sorted_only_if = two ? (for_uniform == F_SORTED ? 1u : 2u) : 0u;
+    const bool sorted_first = first_ok && class_mask(F_SORTED) != 0u;
+    const uint32_t sorted_only_if = class_mask(F_SORTED) == 7u ? 0u : class_mask(F_SORTED);
     const bool hash_first = any_first;
     if (sorted_first) {
         // ---- place_packed16s_kernel: the sorted list of a tile's four reads + their touched bitmaps.  Seven waves per CU on

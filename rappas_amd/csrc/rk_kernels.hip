@@ -86,6 +86,13 @@ __device__ __forceinline__ double shfl_f64(double v, int src, int width) {
 }
 // the read a tile's slot stands for: PlaceArgs::perm when the batch's reads were grouped by their place in the tree (retile_* below)
 __device__ __forceinline__ bool tile_order_given(const PlaceArgs &a) { return a.perm != nullptr && *a.keep_order == 0u; }  // (once per wave)
+// the verdicts of the pre-pass on the batch (retile_decide_kernel: keep_order[0] = the batch keeps its order, keep_order[3] = its sampled
+// k-mers have a row no more often than a random read's) against what this launch was made for (PlaceArgs::only_if)
+__device__ __forceinline__ bool batch_is_mine(const PlaceArgs &a) {
+    if (!a.only_if || !a.perm) return true;
+    const u32 cls = a.keep_order[0] == 0u ? 2u : (a.keep_order[3] != 0u ? 1u : 0u);
+    return ((a.only_if >> cls) & 1u) != 0u;
+}
 __device__ __forceinline__ u64 tile_read(const PlaceArgs &a, u64 slot, bool given) { return given ? (u64)a.perm[slot] : slot; }
 // LDS data exchanged between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be stopped from reordering / caching.
@@ -1547,9 +1554,10 @@ __global__ void __launch_bounds__(256) place_packed16_kernel(PlaceArgs a) {
 // of each other (uniform reads) keeps its order.  Results are written at the read's own index: nothing changes for the caller.
 // ------------------------------------------------------------------------------------------------
 constexpr int RETILE_BINS = 64;
-// hist[0..63]: reads per key; hist[64] / hist[66]: sampled reads without a clade / sampled reads; hist[65]: 1 = keep the order
+// hist[0..63]: reads per key; hist[64] / hist[66]: sampled reads without a clade / sampled reads; hist[65]: 1 = keep the order;
+// hist[67]: sampled k-mers with a row (seven a read); hist[68]: 1 = they are no more than a random read's (retile_decide_kernel)
 template <int BITS>
-__device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &spread) {
+__device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &spread, u32 *with_row = nullptr) {
     const u32 k = a.db.k, wpr = a.words_per_read;
     u32 R = a.lens ? a.lens[r] : a.fixed_len;
     const u32 cap_syms = (wpr * 32u) / BITS;
@@ -1581,6 +1589,12 @@ __device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &s
             best_n = max(best_n, n_);
         }
         key = best;
+        if (with_row) {
+            u32 nz = 0;
+#pragma unroll
+            for (int i = 0; i < NS; i++) nz += w[i] != 0u ? 1u : 0u;  // (a row in the tree's first range counts as none: one in sixty-four)
+            *with_row = nz;
+        }
         spread = best_n < 3u ? 1u : 0u;  // no three of them within a window of each other: a read without a clade (uniform reads)
     }
     return key;
@@ -1590,17 +1604,23 @@ __device__ __forceinline__ u32 retile_read_key(const PlaceArgs &a, u64 r, u32 &s
 template <int BITS>
 __global__ void __launch_bounds__(256) retile_sample_kernel(PlaceArgs a, u32 *hist) {
     const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 64u;
-    u32 spread = 0;
+    u32 spread = 0, with_row = 0;
     const bool on = r < a.n_reads;
-    if (on) (void)retile_read_key<BITS>(a, r, spread);
+    if (on) (void)retile_read_key<BITS>(a, r, spread, &with_row);
     const u64 sp = __ballot(on && spread != 0u), al = __ballot(on);
+    for (int o = 32; o > 0; o >>= 1) with_row += (u32)__shfl_down((int)with_row, o, 64);
     if ((threadIdx.x & 63u) == 0) {
         if (sp) atomicAdd(&hist[RETILE_BINS], (u32)__builtin_popcountll(sp));
         if (al) atomicAdd(&hist[RETILE_BINS + 2], (u32)__builtin_popcountll(al));
+        if (with_row) atomicAdd(&hist[RETILE_BINS + 3], with_row);
     }
 }
-__global__ void retile_decide_kernel(u32 *hist) {
-    if (threadIdx.x == 0) hist[RETILE_BINS + 1] = (hist[RETILE_BINS] * 2u > hist[RETILE_BINS + 2]) ? 1u : 0u;
+// sparse_q16: the share of sampled k-mers with a row (x 65 536) up to which the batch counts as hitting no more often than random reads do
+__global__ void retile_decide_kernel(u32 *hist, u32 sparse_q16) {
+    if (threadIdx.x == 0) {
+        hist[RETILE_BINS + 1] = (hist[RETILE_BINS] * 2u > hist[RETILE_BINS + 2]) ? 1u : 0u;
+        hist[RETILE_BINS + 4] = ((u64)hist[RETILE_BINS + 3] * 65536ull <= (u64)hist[RETILE_BINS + 2] * 7ull * (u64)sparse_q16) ? 1u : 0u;
+    }
 }
 template <int BITS>
 __global__ void __launch_bounds__(256) retile_key_kernel(PlaceArgs a, unsigned char *keys, u32 *hist) {
@@ -2082,7 +2102,7 @@ template <int BITS, int U, int PU, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BITS == 5 ? 2 : 1))) place_packed16s_kernel(PlaceArgs a) {  // (amino acids: 264 registers left to itself, one wave per SIMD)
     constexpr int G = 16, NG = 4, TM = TM_COMPACT, HALF = U / 2, TURNS = 8;
     extern __shared__ u32 lds[];
-    if (a.only_if && a.perm && ((*a.keep_order != 0u) != (a.only_if == 1u))) return;  // (place_hash64_kernel takes this batch)
+    if (!batch_is_mine(a)) return;  // (another first kernel takes this batch)
     const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 wave = threadIdx.x >> 6;
@@ -2583,7 +2603,7 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
     u32 *items = lds + 2 * NS + 64;
     constexpr u32 VOFF = NS + 64;  // lds[VOFF + slot] = the slot's value; lds[NS + lane] = the lane's own word, for key and value operations alike
     if (__builtin_amdgcn_groupstaticsize() != 0u) __builtin_trap();  // (lds_cas_issue takes offsets from the start of the LDS)
-    if (a.only_if && a.perm && ((*a.keep_order != 0u) != (a.only_if == 1u))) return;  // (the other first kernel takes this batch)
+    if (!batch_is_mine(a)) return;  // (another first kernel takes this batch)
     const bool perm_given = tile_order_given(a);
     const u32 lane = threadIdx.x & 63;
     const u32 gi = lane >> 4, li8 = (lane & 15u) * 8u;

@@ -950,6 +950,27 @@ def test_first_kernel_by_the_shape_of_the_batch(rows, n_branches, monkeypatch, d
             assert st["placed"] > 1000
 
 
+def test_first_kernel_by_how_often_the_batch_hits(monkeypatch, dev_lib):
+    """a database that holds a fifth of the k-mer codes, on 20 001 branches: random reads bring ~300 row entries -- the 1 024-slot table of
+    place_hash64_kernel -- but reads cut from the sequence the keys come from hit with every k-mer, four times that.  The pre-pass counts the
+    sampled k-mers that have a row and the batch goes to the small table only when that is no more than a random read's share: a sparse
+    batch, a dense one (rows anywhere in the tree: no clade) and a mixed one all equal the oracle"""
+    monkeypatch.setenv("RK_RETILE_MIN_READS", "0")
+    sdb, g = synth.make_clade_db(k=10, n_branches=20001, genome_len=200_000, seed=9)
+    rng = np.random.default_rng(4)
+    lens = np.diff(sdb.row_offsets.astype(np.int64))
+    b0 = rng.integers(1, np.maximum(2, sdb.n_branches - lens))  # (every row a run of branches somewhere in the tree, not in its stretch's neighbourhood)
+    within = np.arange(int(sdb.row_offsets[-1]), dtype=np.int64) - np.repeat(sdb.row_offsets[:-1].astype(np.int64), lens)
+    sdb = synth.SynthDB(sdb.alphabet, sdb.k, sdb.n_branches, sdb.thr, sdb.thr_log10, sdb.key_codes, sdb.row_offsets,
+                        (np.repeat(b0, lens) + within).astype(np.uint16), sdb.scores, sdb.seed)
+    odb = O.OracleDB.from_synth(sdb)
+    s1, o1 = synth.make_clade_reads(g, 2500, 150, seed=3)          # every k-mer has a row
+    s2, o2 = synth.make_reads(4, 2500, 150, seed=6, var_len=40)    # a fifth of them
+    for seq, off in ((s2, o2), (s1, o1), (np.concatenate([s1, s2]), np.concatenate([o1, o2[1:] + o1[-1]]))):
+        _, _, st = run_case(sdb, odb, seq, off, "direct", 0, "mean")
+        assert st["placed"] > 2000
+
+
 @pytest.mark.parametrize("kernel", ["hash", "sorted"])
 @pytest.mark.parametrize("seed", range(6 + _EXTRA_SEEDS))
 def test_short_row_kernels_of_big_trees_with_scores_from_a_handful_of_values(seed, kernel, request, monkeypatch):
