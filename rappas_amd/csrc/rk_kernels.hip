@@ -2818,14 +2818,17 @@ __global__ void __launch_bounds__(64) place_hash64_kernel(PlaceArgs a) {
 #ifdef RK_STAMPS
                     st_[12] += 1;
 #endif
+                    // (a round under the row's exec mask: the other rows issue nothing, padding lanes of the row add 0 to their own word)
 #pragma unroll
                     for (int p = 0; p < NPL; p++) {
+                        const float dz = __uint_as_float(mask_select(0u, __float_as_uint(d[p]), act[p]));
+                        u32 *const ap = (u32 *)((unsigned char *)lds + at[p]);
 #pragma unroll
                         for (u32 t = 0; t < 4u; t++) {
-                            const u64 on = act[p] & (0xFFFFull << (16u * t));
-                            u32 *at = (u32 *)((unsigned char *)lds + mask_select(own, h[p] + VOFF * 4u, on));
-                            const float v = __uint_as_float(*at);
-                            *at = mask_select(0u, __float_as_uint(v + d[p]), on);
+                            if (gi == t) {
+                                const float vv = __uint_as_float(*ap);
+                                *ap = __float_as_uint(vv + dz);
+                            }
                             wave_lds_fence();
                         }
                     }
