@@ -1538,6 +1538,35 @@ static uint32_t hash_key_limit(uint32_t log_slots = RK_HASH_LOG_SLOTS) {
     return ns - slack;
 }
 
+// ---- which kernel goes first on a windowed tree with short rows, per class of batch ----
+enum First { F_NONE, F_SORTED, F_HASH_BIG, F_HASH_SMALL };
+struct FirstPlan { First for_uniform, for_sparse, for_clade; };
+static FirstPlan first_kernel_plan(const rk_db *db, double est_units, bool hash_small, bool hash_fits, bool sorted_fits, bool verdict) {
+    const uint32_t nb_tree = db->info.n_branches;
+    const bool forced = rk_knob("RK_HASH_ALWAYS") != nullptr;
+    const First table_u = hash_small ? F_HASH_SMALL : F_HASH_BIG;
+    FirstPlan p;
+    if (forced && hash_fits) {
+        p.for_uniform = p.for_sparse = p.for_clade = table_u;
+        return p;
+    }
+    const uint32_t min_u = verdict ? hash_min_uniform(est_units, hash_small) : hash_min_single(est_units, hash_small);
+    p.for_uniform = hash_fits && nb_tree > min_u ? table_u : sorted_fits ? F_SORTED : hash_fits && hash_tree(db, est_units, hash_small) ? table_u : F_NONE;
+    p.for_clade = p.for_sparse = p.for_uniform;
+    if (verdict) {
+        // reads of a clade touch a third of the branches uniform reads do (profiles/r04_lsize_hist.txt: ~500 against ~1 300; max 1 135): their
+        // tables fit the 1 024-slot instantiation -- sixteen waves per CU -- and the few that do not are placed by the large one, launched
+        // behind it on the tiles it hands over
+        const bool clade_small = hash_fits && !hash_small && (rk_knob("RK_HASH_CLADE_SMALL") || nb_tree > hash_min_clade_small(est_units)) && !rk_knob("RK_HASH_BIG_TABLE");
+        p.for_clade = clade_small ? F_HASH_SMALL : hash_fits && nb_tree > hash_min_clade(hash_small) ? table_u : sorted_fits ? F_SORTED : p.for_uniform;
+        // uniform batches whose k-mers hit no more often than a random read's (the pre-pass's second verdict): the uniform estimate of a read's
+        // entries holds, and where that fits the 1 024-slot table the small instantiation serves them (the large one behind it, as for clades)
+        if (hash_fits && !hash_small && !rk_knob("RK_HASH_BIG_TABLE") && est_units * 9.3 <= 0.6 * hash_key_limit(RK_HASH_LOG_SLOTS - 1) && nb_tree > hash_min_uniform(est_units, true))
+            p.for_sparse = F_HASH_SMALL;
+    }
+    return p;
+}
+
 static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     WindowPlan wp = db->wp;
     const uint64_t n_tiles = (a.n_reads + 3) / 4;
@@ -1559,35 +1588,12 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
     TileOrder order;
     if (int rc = order.prepare(db, a, stream, hash_fits || sorted_fits)) return rc;
     const bool first_ok = a.tile_marks != nullptr;  // (no scratch to be had for the marks: place_packed16w_kernel alone)
-    // Which kernel goes first, for a batch of uniform reads and for a batch of reads of a clade.  When the batch went through the re-tiling
-    // pre-pass (a.perm) its verdict on the batch's shape is on the device: if the two choices differ both kernels are launched and one of
-    // them returns at once (PlaceArgs::only_if).  Without the verdict (small batches) one rule serves both.
-    enum First { F_NONE, F_SORTED, F_HASH_BIG, F_HASH_SMALL };
-    const uint32_t nb_tree = db->info.n_branches;
-    const bool forced = rk_knob("RK_HASH_ALWAYS") != nullptr;
+    // Which kernel goes first for each class of batch (first_kernel_plan); when the batch went through the re-tiling pre-pass (a.perm) its
+    // verdicts are on the device: the kernels that differ between the classes are launched side by side and return at once when the batch
+    // is not theirs (PlaceArgs::only_if).  Without the verdicts (small batches) one rule serves all.
     const bool verdict = a.perm != nullptr;
-    const First table_u = hash_small ? F_HASH_SMALL : F_HASH_BIG;
-    First for_uniform, for_clade;
-    if (forced && hash_fits) {
-        for_uniform = for_clade = table_u;
-    } else {
-        const uint32_t min_u = verdict ? hash_min_uniform(est_units, hash_small) : hash_min_single(est_units, hash_small);
-        for_uniform = hash_fits && nb_tree > min_u ? table_u : sorted_fits ? F_SORTED : hash_fits && hash_tree(db, est_units, hash_small) ? table_u : F_NONE;
-        for_clade = for_uniform;
-        if (verdict) {
-            // reads of a clade touch a third of the branches uniform reads do (profiles/r04_lsize_hist.txt: ~500 against ~1 300; max 1 135): their
-            // tables fit the 1 024-slot instantiation -- sixteen waves per CU -- and the few that do not are placed by the large one, launched
-            // behind it on the tiles it hands over
-            const bool clade_small = hash_fits && !hash_small && (rk_knob("RK_HASH_CLADE_SMALL") || nb_tree > hash_min_clade_small(est_units)) && !rk_knob("RK_HASH_BIG_TABLE");
-            for_clade = clade_small ? F_HASH_SMALL : hash_fits && nb_tree > hash_min_clade(hash_small) ? table_u : sorted_fits ? F_SORTED : for_uniform;
-        }
-    }
-    // uniform batches whose k-mers hit no more often than a random read's (the pre-pass's second verdict): the uniform estimate of a read's
-    // entries holds, and where that fits the 1 024-slot table the small instantiation serves them (the large one behind it, as for clades)
-    First for_sparse = for_uniform;
-    if (verdict && !forced && hash_fits && !hash_small && !rk_knob("RK_HASH_BIG_TABLE") && est_units * 9.3 <= 0.6 * hash_key_limit(RK_HASH_LOG_SLOTS - 1) &&
-        nb_tree > hash_min_uniform(est_units, true))
-        for_sparse = F_HASH_SMALL;
+    const FirstPlan plan = first_kernel_plan(db, est_units, hash_small, hash_fits, sorted_fits, verdict);
+    const First for_uniform = plan.for_uniform, for_sparse = plan.for_sparse, for_clade = plan.for_clade;
     // every distinct kernel once, with the classes of batches it serves (PlaceArgs::only_if: bit 0 uniform reads that hit often, bit 1
     // uniform reads that hit like random ones, bit 2 reads of a clade; all three = unconditional)
     const First by_class[3] = {for_uniform, for_sparse, for_clade};
@@ -1893,7 +1899,7 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
     if (!db) return "";
     Geometry g;
     rk_db *m = const_cast<rk_db *>(db);
-    char buf[320];
+    char buf[800];
     if (db->indexed && db->lanes_per_read == 0) {
         WgGeometry wg;
         if (choose_wg_geometry(db, wg, 7) != RK_OK) return "";
@@ -1904,19 +1910,30 @@ extern "C" const char *rk_kernel_name(const rk_db *db) {
         return m->kernel_name.c_str();
     }
     if (use_windowed(db, 7, 16)) {
-        const double est_name = (db->info.bits_per_symbol == 5 ? 100.0 - db->info.k + 1 : 150.0 - db->info.k + 1) * db->wp.units_per_code;  // (the reads of BASELINE's configs)
-        const bool hash_fits = hash_capable(db) && (rk_knob("RK_HASH_ALWAYS") || 141.0 * db->wp.units_per_code * 9.3 <= 0.8 * hash_key_limit());
-        const bool small_name = hash_small_table(full_hit_entries(db, db->info.bits_per_symbol == 5 ? 100u : 150u));
-        const bool band = hash_fits && !rk_knob("RK_HASH_ALWAYS") && db->wp.stream && db->info.n_branches > hash_min_uniform(est_name, small_name) && db->info.n_branches <= hash_min_clade(small_name);
-        if (hash_fits && (band || hash_tree(db, est_name, small_name)))
+        // (for the reads of BASELINE's configs -- 150 bases / 100 residues -- and a batch large enough for the pre-pass's verdicts)
+        const uint32_t syms_name = db->info.bits_per_symbol == 5 ? 100u : 150u;
+        const double est_name = (double)(syms_name - db->info.k + 1) * db->wp.units_per_code;
+        const bool hash_fits = hash_capable(db) && (rk_knob("RK_HASH_ALWAYS") || est_name * 9.3 <= 0.8 * hash_key_limit());
+        const bool small_name = hash_small_table(full_hit_entries(db, syms_name));
+        const bool sorted_name = db->wp.stream && !rk_knob("RK_NO_WSTREAM") && (est_name <= 1.25 * RK_WSTREAM_MAX_UNITS || rk_knob("RK_WSTREAM_ALWAYS"));
+        const FirstPlan pl = first_kernel_plan(db, est_name, small_name, hash_fits, sorted_name, true);
+        auto what = [](First f) { return f == F_HASH_SMALL ? "place_hash64_kernel with 1 024 slots (the 2 048-slot one behind it)" : f == F_HASH_BIG ? "place_hash64_kernel" : f == F_SORTED ? "place_packed16s_kernel" : "place_packed16w_kernel"; };
+        const First shown = pl.for_uniform == F_HASH_BIG || pl.for_uniform == F_HASH_SMALL ? pl.for_uniform : (pl.for_sparse == F_HASH_SMALL || pl.for_clade == F_HASH_SMALL || pl.for_clade == F_HASH_BIG) && pl.for_uniform == F_NONE ? pl.for_clade : pl.for_uniform;
+        if (shown == F_HASH_BIG || shown == F_HASH_SMALL) {
+            const uint32_t ls = shown == F_HASH_SMALL ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS;
+            char other[360] = "";
+            if (pl.for_clade != pl.for_uniform || pl.for_sparse != pl.for_uniform)
+                snprintf(other, sizeof(other), "; batches of 32 768 reads or more, judged on the device: clade-shaped -> %s%s%s", what(pl.for_clade),
+                         pl.for_sparse != pl.for_uniform ? ", uniform and sparse-hit -> " : "", pl.for_sparse != pl.for_uniform ? what(pl.for_sparse) : "");
             snprintf(buf, sizeof(buf), "place_hash64_kernel<BITS=%u,U=%d,NPL=%d,PU=%d,LOGS=%u> %u slots, <= %u keys a read%s (+ place_packed16w_kernel for the tiles it hands over; windows=%u x %u branches)",
-                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, small_name ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS,
-                     1u << (small_name ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS), hash_key_limit(small_name ? RK_HASH_LOG_SLOTS - 1 : RK_HASH_LOG_SLOTS),
-                     band ? (db->info.n_branches > hash_min_single(est_name, small_name) ? " | place_packed16s_kernel for batches of clade-shaped reads" : " for batches of uniform reads of 32 768 or more | place_packed16s_kernel otherwise") : "",
-                     db->wp.n_win, db->wp.W);
-        else if (db->wp.stream && !rk_knob("RK_NO_WSTREAM"))
-            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches (+ place_packed16w_kernel for the tiles it hands over)",
-                     db->info.bits_per_symbol, db->info.bits_per_symbol == 5 ? 7 : 9, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W);
+                     db->info.bits_per_symbol, RK_HRING, RK_HNPL, db->info.bits_per_symbol == 5 ? 2 : 3, ls, 1u << ls, hash_key_limit(ls), other, db->wp.n_win, db->wp.W);
+        } else if (pl.for_uniform == F_SORTED) {
+            char other[360] = "";
+            if (pl.for_clade != pl.for_uniform || pl.for_sparse != pl.for_uniform)
+                snprintf(other, sizeof(other), "; batches of 32 768 reads or more, judged on the device: clade-shaped -> %s, uniform and sparse-hit -> %s", what(pl.for_clade), what(pl.for_sparse));
+            snprintf(buf, sizeof(buf), "place_packed16s_kernel<BITS=%u,U=8,PU=%d,WIDE=%d> windows=%u x %u branches%s (+ place_packed16w_kernel for the tiles it hands over)",
+                     db->info.bits_per_symbol, db->info.bits_per_symbol == 5 ? 7 : 9, db->wp.W > 512 ? 1 : 0, db->wp.n_win, db->wp.W, other);
+        }
         else
         snprintf(buf, sizeof(buf), "place_packed16w_kernel<BITS=%u,U=%d,PU=9> windows=%u x %u branches lds/wave=%zuB main=%u work=%u",
                  db->info.bits_per_symbol, RK_WRING, db->wp.n_win, db->wp.W, (size_t)16 * (db->wp.s_stride + db->wp.main_cap + db->wp.work_cap),

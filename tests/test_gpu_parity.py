@@ -937,12 +937,12 @@ def test_first_kernel_by_the_shape_of_the_batch(rows, n_branches, monkeypatch, d
     db = ra.PhyloKmerDB.from_synth(sdb)
     name = db.kernel_name()
     db.close()
-    if n_branches == 60001:  # (uniform batches: the large table; clade-shaped ones: the small table with the large one behind it for the tiles it hands over)
-        assert "place_hash64_kernel" in name and "place_packed16s_kernel" not in name, name
-    elif n_branches == 30001:  # (beyond the small table's clade crossing: the hash kernel alone)
-        assert "place_hash64_kernel" in name and "place_packed16s_kernel" not in name and "LOGS=10" in name, name
-    else:
-        assert "place_hash64_kernel" in name and "place_packed16s_kernel" in name and ("LOGS=10" if rows.endswith("small-table") else "LOGS=11") in name, name
+    # (the name spells the plan out: the kernel of uniform batches first, then the classes of batches that take another)
+    assert "place_hash64_kernel" in name and ("LOGS=10" in name) == rows.endswith("small-table"), name
+    if rows == "sparse":  # (few row units a read: clade-shaped batches change over at ~19 300 branches)
+        assert ("clade-shaped -> place_packed16s_kernel" if n_branches == 12001 else "clade-shaped -> place_hash64_kernel with 1 024 slots") in name, name
+    if rows == "dense":
+        assert "clade-shaped -> place_hash64_kernel with 1 024 slots" in name, name
     s2, o2 = synth.make_reads(4, 2500, 150, seed=6, var_len=60, amb_rate=0.001, bad_rate=0.002)
     for seq, off in ((s1, o1), (s2, o2), (np.concatenate([s1, s2]), np.concatenate([o1, o2[1:] + o1[-1]]))):
         for K in (7, 12):
