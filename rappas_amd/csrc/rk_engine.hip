@@ -1644,7 +1644,8 @@ static int launch_windowed(const rk_db *db, PlaceArgs a, hipStream_t stream) {
         }
         if (small_on_trust && a.marked_list) {  // the tiles the small table handed over: the large one next, then place_packed16w_kernel for what is left
             if (int rc = compact_marks()) return rc;
-            if (int rc = launch_hash(RK_HASH_LOG_SLOTS, 0u, 1u)) return rc;
+            const uint32_t m = class_mask(F_HASH_SMALL);  // (only for the batches the small table took)
+            if (int rc = launch_hash(RK_HASH_LOG_SLOTS, m == 7u ? 0u : m, 1u)) return rc;
         }
     }
     const bool sorted_first = first_ok && class_mask(F_SORTED) != 0u;
