@@ -25,10 +25,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: enough for about 1-10 s of GPU time: 200 for C1/C2/C4, 10 for C3/C5s/C5m, 3 for C5)")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default: 10, or 1 for the long configs)")
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "C5mini", "C5s", "C5m", "T4k", "T8k", "T20k", "T40k", "T64k", "L9k", "L16k"],
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "C5mini", "C5s", "C5m", "T4k", "T8k", "T20k", "T40k", "T64k", "P20k", "L9k", "L16k"],
                     help="C2 = the configuration BASELINE's metric is quoted on (default); C3 = C2's DB with 1.25e8 reads per GPU "
                          "(1e9 reads over 8 GPUs); C5 = 10k-leaf tree, k=12, ~200 GB DB generated on the device, 1.25e7 x 250 bp per GPU; "
-                         "T4k / T8k / T20k / T40k / T64k = C2's database and reads on trees of 3 999 / 7 999 / 19 999 / 39 999 / 65 535 branches; L9k / L16k = rows of 400 / 1 000 entries "
+                         "T4k / T8k / T20k / T40k / T64k = C2's database and reads on trees of 3 999 / 7 999 / 19 999 / 39 999 / 65 535 branches; P20k = amino acids k=5, C4-like rows, 19 999 branches; L9k / L16k = rows of 400 / 1 000 entries "
                          "on 9 001 / 15 999 branches (not BASELINE configs)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's count)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per read (0=auto, 8/16/32/64)")
@@ -56,7 +56,7 @@ def parse():
                     help="launcher / rank bookkeeping rehearsal WITHOUT a GPU: no engine, no placement, a step is a 5 ms sleep; "
                          "the JSON line says so and carries no rate (tests of --gpus N on CPU)")
     a = ap.parse_args()
-    long_cfg = {"C3": 10, "C5": 3, "C5s": 10, "C5m": 5, "C5mini": 20, "T4k": 40, "T8k": 30, "T20k": 30, "T40k": 20, "T64k": 20, "L9k": 20, "L16k": 10}
+    long_cfg = {"C3": 10, "C5": 3, "C5s": 10, "C5m": 5, "C5mini": 20, "T4k": 40, "T8k": 30, "T20k": 30, "T40k": 20, "T64k": 20, "P20k": 20, "L9k": 20, "L16k": 10}
     if a.steps <= 0:
         a.steps = long_cfg.get(a.config, 200)
     if a.warmup < 0:

@@ -25,6 +25,8 @@ CONFIGS = {
     "T20k": (4, 10, 10_000, 786_432, 10_000_000, 150, 2_000_000),
     "T40k": (4, 10, 20_000, 786_432, 10_000_000, 150, 2_000_000),  # (39 999 branches: between the two crossings of the short-row kernels)
     "T64k": (4, 10, 32_768, 786_432, 10_000_000, 150, 2_000_000),
+    # a protein tree of 19 999 branches with C4-like rows (a quarter of the 5-mers present): scripts/hash_crossover.py aa as a bench line
+    "P20k": (20, 5, 10_000, 786_432, 10_000_000, 100, 2_000_000),
     # not BASELINE configs either: long rows on trees between the dense kernels' and the workgroup-per-read kernel's regimes (a quarter
     # of the 9-mers present; rows of 400 entries on 9 001 branches, of 1 000 on 15 999: scripts/long_rows_big_tree.py as bench lines)
     "L9k": (4, 9, 4_501, 65_536, 26_214_400, 150, 300_000),

@@ -55,7 +55,7 @@ def test_world_size_mismatch_is_an_error():
     assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
 
 
-@pytest.mark.parametrize("config,reads", [("C1", "1000"), ("C4", "100000"), ("C3", "2000000"), ("T4k", "200000"), ("T40k", "100000"), ("T64k", "100000")])
+@pytest.mark.parametrize("config,reads", [("C1", "1000"), ("C4", "100000"), ("C3", "2000000"), ("T4k", "200000"), ("T40k", "100000"), ("T64k", "100000"), ("P20k", "100000")])
 def test_other_configs_have_a_bench_leg(config, reads):
     line = run_bench("--config", config, "--reads", reads, "--steps", "2", "--warmup", "1", "--cpu-sample", "2000", "--verify", "500")
     assert line["config"]["workload"].startswith(config + ":")
